@@ -1,0 +1,261 @@
+/*
+ * rt_dp -- batch evaluator for the raytracer_datapath `UnifiedDatapath` module
+ * on AMD Instinct MI355X (gfx950).  C ABI of librt_dp.so.
+ *
+ * The RTL consumes one EnhancedInputBundle per clock on a Decoupled port and
+ * delivers one EnhancedOutputBundle per record, in order, 12 registers later
+ * (reference: src/main/scala/raytracer_datapath/UnifiedDatapath.scala:50-59,
+ * :1168-1284).  This library evaluates the same function over whole batches:
+ * results are bit-identical to the RTL's HardFloat arithmetic (round to
+ * nearest even, subnormals kept, canonical NaN 0x7FC00000, the RTL's
+ * compare-select and sort-network ordering, no fused multiply-add).
+ *
+ * All citations are file:line under the reference's
+ * src/main/scala/raytracer_datapath/ unless a longer path is given.
+ *
+ * Conventions
+ *   - Plain pointers and sizes only.  Every array is owned by the caller and
+ *     is neither retained nor freed by the library.
+ *   - A batch is opcode-sorted: one segment per opcode, laid out as a
+ *     structure of arrays.  Result i of a segment belongs to op i of that
+ *     segment (the RTL's in-order pipe).  Within the Euclidean and within the
+ *     angular segment, beats are in stream order: the accumulator registers
+ *     run through them exactly as through the RTL's stage 10 / stage 9.
+ *   - Functions return RT_DP_OK (0) or a negative RT_DP_E* code and never
+ *     throw or abort; rt_dp_last_error() describes the last failure of the
+ *     calling thread.
+ */
+#ifndef RT_DP_H
+#define RT_DP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_DP_VERSION_MAJOR 0
+#define RT_DP_VERSION_MINOR 1
+
+/* UnifiedDatapathOpCode, IOSpec.scala:10-24 */
+enum rt_dp_opcode {
+    RT_DP_OP_TRIANGLE  = 0, /* ray-triangle test                                  */
+    RT_DP_OP_QUADBOX   = 1, /* ray vs four AABBs, sorted                          */
+    RT_DP_OP_EUCLIDEAN = 2, /* one 16-element beat of sum((a-b)^2), accumulated   */
+    RT_DP_OP_ANGULAR   = 3  /* one 8-element beat of dot(q,c) and dot(c,c), acc.  */
+};
+
+enum rt_dp_status {
+    RT_DP_OK       = 0,
+    RT_DP_EINVAL   = -1, /* malformed argument (bad struct_size, unknown flag, count too large) */
+    RT_DP_ENULL    = -2, /* a required pointer is NULL (e.g. an operand array of a non-empty segment) */
+    RT_DP_EOPCODE  = -3, /* opcode > 3 in a bundle stream (cannot occur in the 2-bit RTL field) */
+    RT_DP_EHIP     = -4, /* HIP runtime error; see rt_dp_last_error() */
+    RT_DP_ENODEV   = -5, /* no usable gfx950 device */
+    RT_DP_EALIGN   = -6, /* a device array is not 4-byte aligned */
+    RT_DP_ENOMEM   = -7  /* host or device allocation failed */
+};
+
+/* rt_dp_op_batch.flags */
+#define RT_DP_F_DEVICE_PTRS 0x1u /* every array pointer in the batch and in the result is a device pointer
+                                    of the context's GPU; without it they are host pointers and the library
+                                    stages them through its own device buffers */
+#define RT_DP_F_ALL_FLAGS   0x1u
+
+/* ---- opcode 1: Quadbox --------------------------------------------------
+ * Live operands of EnhancedInputBundle for this opcode (IOSpec.scala:54-91,
+ * :106-133; dataflow UnifiedDatapath.scala:167-220, :346-398, :534-631,
+ * :1117-1132): 34 f32 per op.  aabb[b] lists x_min,y_min,z_min,x_max,y_max,z_max. */
+typedef struct rt_dp_box_in {
+    const float *org[3];     /* ray.origin.{x,y,z} */
+    const float *dir[3];     /* ray.dir.{x,y,z}   (only its sign / zero test is used) */
+    const float *inv[3];     /* ray.inv.{x,y,z} */
+    const float *extent;     /* ray.extent */
+    const float *aabb[4][6]; /* aabb(b).{x_min,y_min,z_min,x_max,y_max,z_max} */
+} rt_dp_box_in;
+
+/* tmin_out[k], k = 0..3: hits first, nearest first; misses carry +Inf
+ * (IOSpec.scala:142-149).  flags packs the remaining output fields:
+ *   bits 3:0   isIntersect[0..3]   (bit k <-> output slot k)
+ *   bits 11:4  boxIndex[0..3], two bits each, slot k at bits 5+2k:4+2k        */
+typedef struct rt_dp_box_out {
+    float    *tmin_out[4];
+    uint32_t *flags;
+} rt_dp_box_out;
+
+#define RT_DP_BOX_ISECT(flags, k) (((flags) >> (k)) & 1u)
+#define RT_DP_BOX_INDEX(flags, k) (((flags) >> (4 + 2 * (k))) & 3u)
+
+/* ---- opcode 0: Triangle -------------------------------------------------
+ * Live operands (IOSpec.scala:54-71, :93-99; dataflow UnifiedDatapath.scala:
+ * :118-166, :293-345, :486-533, :688-726, :753-781, :844-871, :898-913,
+ * :990-1005, :1087-1116): 15 f32 + the three 2-bit axis selectors.           */
+typedef struct rt_dp_tri_in {
+    const float    *org[3];    /* ray.origin */
+    const float    *shear[3];  /* ray.shear */
+    const float    *vtx[3][3]; /* triangle.{A,B,C}.{x,y,z} */
+    const uint32_t *k;         /* ray.kx | ray.ky << 2 | ray.kz << 4; a selector value of 3 reads z,
+                                  like Float3.at (IOSpec.scala:41-51) */
+} rt_dp_tri_in;
+
+typedef struct rt_dp_tri_out {
+    float    *t_num;   /* always written, hit or not */
+    float    *t_denom;
+    uint32_t *hit;     /* triangle_hit, 0 or 1 */
+} rt_dp_tri_out;
+
+/* ---- opcodes 2 and 3: Euclidean / angular beats ---------------------------
+ * a, b: the two vectors of the segment, beat after beat, row-major
+ *   Euclidean: [n][16] = euclidean_a / euclidean_b            (IOSpec.scala:128-132)
+ *   angular:   [n][8]  = query (euclidean_a[0..7]) / candidate (euclidean_b[0..7])
+ *                                                              (IOSpec.scala:229-243)
+ * ctl[i] = euclidean_mask | euclidean_reset_accum << 16 (mask bit j <-> element j;
+ * the angular op looks at mask bits 7:0 only).  A set reset bit marks the LAST
+ * beat of a vector pair: that beat's result still includes it, and the
+ * accumulator restarts from +0 on the next beat (UnifiedDatapath.scala:1146-1152,
+ * :1055-1062).                                                               */
+typedef struct rt_dp_vec_in {
+    const float    *a;
+    const float    *b;
+    const uint32_t *ctl;
+} rt_dp_vec_in;
+
+#define RT_DP_CTL(mask, reset) ((uint32_t)(mask) | ((uint32_t)((reset) != 0) << 16))
+
+typedef struct rt_dp_euc_out {
+    float *accumulator; /* euclidean_accumulator after each beat */
+} rt_dp_euc_out;
+
+typedef struct rt_dp_ang_out {
+    float *dot_product; /* angular_dot_product after each beat */
+    float *norm;        /* angular_norm after each beat */
+} rt_dp_ang_out;
+
+/* ---- the batch ------------------------------------------------------------ */
+typedef struct rt_dp_op_batch {
+    uint32_t     struct_size; /* sizeof(rt_dp_op_batch) */
+    uint32_t     flags;       /* RT_DP_F_* */
+    uint64_t     n[4];        /* ops (beats) per opcode segment, indexed by rt_dp_opcode */
+    rt_dp_tri_in tri;
+    rt_dp_box_in box;
+    rt_dp_vec_in euc;
+    rt_dp_vec_in ang;
+} rt_dp_op_batch;
+
+typedef struct rt_dp_result_batch {
+    uint32_t      struct_size; /* sizeof(rt_dp_result_batch) */
+    uint32_t      reserved;    /* 0 */
+    rt_dp_tri_out tri;
+    rt_dp_box_out box;
+    rt_dp_euc_out euc;
+    rt_dp_ang_out ang;
+} rt_dp_result_batch;
+
+/* ---- contexts ---------------------------------------------------------------
+ * One context = one datapath instance: it owns the three accumulator registers
+ * (UnifiedDatapath.scala:1031-1032, :1136), a HIP stream and grow-only staging
+ * buffers on one GPU.  Distinct contexts may be used from distinct threads; a
+ * single context is not re-entrant.                                            */
+typedef struct rt_dp_ctx rt_dp_ctx;
+
+/* RaytracerParams, UnifiedDatapath.scala:13-23.  Like the RTL's elaboration
+ * asserts (:36-47) rt_dp_create rejects io_recorded_float != 0,
+ * internal_recorded_float != 1 and support_euclidean not in {0, 16}.
+ * support_euclidean == 0 is the baseline datapath: opcodes 2 and 3 flow through
+ * untouched, so their result arrays are filled with zeros.                     */
+typedef struct rt_dp_config {
+    uint32_t struct_size;             /* sizeof(rt_dp_config) */
+    int32_t  device;                  /* HIP device ordinal, -1 = current device */
+    uint32_t io_recorded_float;       /* must be 0 */
+    uint32_t internal_recorded_float; /* must be 1 */
+    uint32_t support_euclidean;       /* 0 (None) or 16 (Some(16)) */
+    uint32_t reserved;
+} rt_dp_config;
+
+int  rt_dp_create(const rt_dp_config *cfg /* NULL = current device, Some(16) */, rt_dp_ctx **out);
+void rt_dp_destroy(rt_dp_ctx *ctx);
+
+/* Replaces driving UnifiedDatapath.in / .out for one batch (the chiseltest
+ * enqueueSeq / waitForValid+peek loop of src/test/scala/raytracer_datapath/
+ * Datapath_test.scala:275-302, :341-375, :476-496).  Synchronous: results are
+ * visible when it returns.  rt_dp_eval uses a per-thread default context on
+ * the current device.                                                          */
+int rt_dp_eval(const rt_dp_op_batch *in, rt_dp_result_batch *out);
+int rt_dp_eval_ctx(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *out);
+
+/* Asynchronous form for callers that keep their streams in HBM: requires
+ * RT_DP_F_DEVICE_PTRS, enqueues the kernels on `hip_stream` (a hipStream_t;
+ * NULL = the context's own stream) and returns without synchronising.         */
+int rt_dp_launch(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *out, void *hip_stream);
+int rt_dp_synchronize(rt_dp_ctx *ctx);
+
+/* The accumulator registers: {euclidean, angular dot, angular norm}.
+ * rt_dp_reset is the RTL's reset (all three to +0).                            */
+int rt_dp_reset(rt_dp_ctx *ctx);
+int rt_dp_get_accum(rt_dp_ctx *ctx, float acc[3]);
+int rt_dp_set_accum(rt_dp_ctx *ctx, const float acc[3]);
+
+/* ---- record-at-a-time image of the RTL ports --------------------------------
+ * EnhancedInputBundle / EnhancedOutputBundle (IOSpec.scala:106-173) with every
+ * FP field as its IEEE-754 bit pattern.  rt_dp_eval_bundles takes a stream of
+ * input records in arrival order (any opcode mix), partitions it by opcode,
+ * evaluates it on the GPU and writes one output record per input record in the
+ * same order.  Output fields that do not belong to the record's opcode are 0;
+ * the two *_reset_accum outputs echo the input bit for every opcode
+ * (UnifiedDatapath.scala:1205, :1254, :1267-1268); with support_euclidean == 0
+ * the euclidean/angular outputs do not exist and are written as 0.             */
+typedef struct rt_dp_f3 { uint32_t x, y, z; } rt_dp_f3;
+typedef struct rt_dp_ray {
+    rt_dp_f3 origin, dir, inv;
+    uint32_t extent;
+    uint32_t kx, ky, kz;
+    rt_dp_f3 shear;
+} rt_dp_ray;
+typedef struct rt_dp_aabb { uint32_t x_min, y_min, z_min, x_max, y_max, z_max; } rt_dp_aabb;
+typedef struct rt_dp_triangle { rt_dp_f3 A, B, C; } rt_dp_triangle;
+
+typedef struct rt_dp_input_bundle {
+    uint32_t       opcode;
+    rt_dp_ray      ray;
+    rt_dp_aabb     aabb[4];
+    rt_dp_triangle triangle;
+    uint32_t       euclidean_a[16];
+    uint32_t       euclidean_b[16];
+    uint32_t       euclidean_mask;
+    uint32_t       euclidean_reset_accum;
+} rt_dp_input_bundle;
+
+typedef struct rt_dp_output_bundle {
+    uint32_t opcode;
+    uint32_t tmin_out[4];
+    uint32_t isIntersect[4];
+    uint32_t boxIndex[4];
+    uint32_t t_num, t_denom;
+    uint32_t triangle_hit;
+    uint32_t euclidean_accumulator;
+    uint32_t euclidean_reset_accum;
+    uint32_t angular_dot_product;
+    uint32_t angular_norm;
+    uint32_t angular_reset_accum;
+} rt_dp_output_bundle;
+
+int rt_dp_eval_bundles(rt_dp_ctx *ctx, const rt_dp_input_bundle *in, rt_dp_output_bundle *out, uint64_t n);
+
+/* ---- tuning and diagnostics ---------------------------------------------------
+ * Kernel-shape knobs (0 = library default), for A/B measurements; results do not
+ * depend on them.  ops_per_lane: consecutive box / triangle ops one lane owns
+ * (1, 2 or 4; lowered automatically when an array is not 8- / 16-byte aligned).
+ * nontemporal: streaming loads and stores carry the `nt` cache hint.  vec_tile:
+ * nominal beats per workgroup for opcodes 2/3 (multiple of 256).  The same knobs
+ * are read once per context from RT_DP_OPS_PER_LANE, RT_DP_NONTEMPORAL and
+ * RT_DP_VEC_TILE.  No counterpart in the reference.                              */
+int rt_dp_set_tuning(rt_dp_ctx *ctx, int ops_per_lane, int nontemporal, int vec_tile);
+
+const char *rt_dp_last_error(void);
+const char *rt_dp_version(void);
+int         rt_dp_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_DP_H */

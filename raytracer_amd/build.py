@@ -1,0 +1,65 @@
+"""In-tree build of librt_dp.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m raytracer_amd.build [--force]
+
+Flags that matter for bit-exactness: -ffp-contract=off (the RTL has separate
+multiplier and adder units, never a fused multiply-add), no fast-math, and f32
+denormals left enabled (the hipcc default for gfx9).
+"""
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIBDIR = os.path.join(_HERE, "lib")
+LIB = os.path.join(LIBDIR, "librt_dp.so")
+ROOT = os.path.dirname(_HERE)
+
+ARCH = "gfx950"
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+          "-fno-gpu-flush-denormals-to-zero", "-Wall", "-Wno-unused-function",
+          "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+SOURCES = ["kernels.hip", "api.cpp"]
+HOST_TOOLS = {"rt_dp_replay": ["rt_dp_replay.cpp"]}
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "rt_dp.h"), __file__]
+    if force or _stale(LIB, deps):
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-x", "hip"] + COMMON + ["-shared", "-o", LIB] + \
+              [os.path.join(CSRC, s) for s in SOURCES]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    for tool, srcs in HOST_TOOLS.items():
+        paths = [os.path.join(CSRC, s) for s in srcs]
+        if not all(os.path.exists(p) for p in paths):
+            continue
+        out = os.path.join(LIBDIR, tool)
+        if force or _stale(out, paths + [LIB]):
+            cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", out] + paths + \
+                  ["-L", LIBDIR, "-lrt_dp", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,312 @@
+"""ctypes binding of librt_dp.so (the C ABI declared in include/rt_dp.h).
+
+There is no CPU fallback: loading fails loudly when the HIP library has not been
+built, and every call goes through the C ABI.
+
+Arrays may be numpy arrays (host pointers: the library stages them) or torch
+CUDA tensors (device pointers, RT_DP_F_DEVICE_PTRS: the caller's HBM is used in
+place).  A batch must not mix the two kinds.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librt_dp.so")
+
+OP_TRIANGLE, OP_QUADBOX, OP_EUCLIDEAN, OP_ANGULAR = 0, 1, 2, 3
+F_DEVICE_PTRS = 0x1
+
+OK, EINVAL, ENULL, EOPCODE, EHIP, ENODEV, EALIGN, ENOMEM = 0, -1, -2, -3, -4, -5, -6, -7
+
+# operand order of the SoA segments (matches rt_dp_box_in / rt_dp_tri_in)
+BOX_FIELDS = (["org_x", "org_y", "org_z", "dir_x", "dir_y", "dir_z", "inv_x", "inv_y", "inv_z", "extent"] +
+              ["b%d_%s" % (b, f) for b in range(4) for f in ("x_min", "y_min", "z_min", "x_max", "y_max", "z_max")])
+TRI_FIELDS = ["org_x", "org_y", "org_z", "shear_x", "shear_y", "shear_z",
+              "ax", "ay", "az", "bx", "by", "bz", "cx", "cy", "cz"]
+
+_fp = C.c_void_p
+
+
+class BoxIn(C.Structure):
+    _fields_ = [("org", _fp * 3), ("dir", _fp * 3), ("inv", _fp * 3), ("extent", _fp), ("aabb", (_fp * 6) * 4)]
+
+
+class BoxOut(C.Structure):
+    _fields_ = [("tmin_out", _fp * 4), ("flags", _fp)]
+
+
+class TriIn(C.Structure):
+    _fields_ = [("org", _fp * 3), ("shear", _fp * 3), ("vtx", (_fp * 3) * 3), ("k", _fp)]
+
+
+class TriOut(C.Structure):
+    _fields_ = [("t_num", _fp), ("t_denom", _fp), ("hit", _fp)]
+
+
+class VecIn(C.Structure):
+    _fields_ = [("a", _fp), ("b", _fp), ("ctl", _fp)]
+
+
+class EucOut(C.Structure):
+    _fields_ = [("accumulator", _fp)]
+
+
+class AngOut(C.Structure):
+    _fields_ = [("dot_product", _fp), ("norm", _fp)]
+
+
+class OpBatch(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("n", C.c_uint64 * 4),
+                ("tri", TriIn), ("box", BoxIn), ("euc", VecIn), ("ang", VecIn)]
+
+
+class ResultBatch(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32),
+                ("tri", TriOut), ("box", BoxOut), ("euc", EucOut), ("ang", AngOut)]
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("io_recorded_float", C.c_uint32),
+                ("internal_recorded_float", C.c_uint32), ("support_euclidean", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class F3(C.Structure):
+    _fields_ = [("x", C.c_uint32), ("y", C.c_uint32), ("z", C.c_uint32)]
+
+
+class Ray(C.Structure):
+    _fields_ = [("origin", F3), ("dir", F3), ("inv", F3), ("extent", C.c_uint32),
+                ("kx", C.c_uint32), ("ky", C.c_uint32), ("kz", C.c_uint32), ("shear", F3)]
+
+
+class AABB(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("x_min", "y_min", "z_min", "x_max", "y_max", "z_max")]
+
+
+class Triangle(C.Structure):
+    _fields_ = [("A", F3), ("B", F3), ("C", F3)]
+
+
+class InputBundle(C.Structure):
+    _fields_ = [("opcode", C.c_uint32), ("ray", Ray), ("aabb", AABB * 4), ("triangle", Triangle),
+                ("euclidean_a", C.c_uint32 * 16), ("euclidean_b", C.c_uint32 * 16),
+                ("euclidean_mask", C.c_uint32), ("euclidean_reset_accum", C.c_uint32)]
+
+
+class OutputBundle(C.Structure):
+    _fields_ = [("opcode", C.c_uint32), ("tmin_out", C.c_uint32 * 4), ("isIntersect", C.c_uint32 * 4),
+                ("boxIndex", C.c_uint32 * 4), ("t_num", C.c_uint32), ("t_denom", C.c_uint32),
+                ("triangle_hit", C.c_uint32), ("euclidean_accumulator", C.c_uint32),
+                ("euclidean_reset_accum", C.c_uint32), ("angular_dot_product", C.c_uint32),
+                ("angular_norm", C.c_uint32), ("angular_reset_accum", C.c_uint32)]
+
+
+assert C.sizeof(InputBundle) == 84 * 4 and C.sizeof(OutputBundle) == 21 * 4
+
+EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize",
+           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning",
+           "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
+
+
+class RtDpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("rt_dp error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load librt_dp.so.  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("librt_dp.so not found at %s: build it with `python -m raytracer_amd.build` "
+                          "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.rt_dp_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.rt_dp_destroy.argtypes = [vp]
+    L.rt_dp_destroy.restype = None
+    L.rt_dp_eval.argtypes = [C.POINTER(OpBatch), C.POINTER(ResultBatch)]
+    L.rt_dp_eval_ctx.argtypes = [vp, C.POINTER(OpBatch), C.POINTER(ResultBatch)]
+    L.rt_dp_launch.argtypes = [vp, C.POINTER(OpBatch), C.POINTER(ResultBatch), vp]
+    L.rt_dp_synchronize.argtypes = [vp]
+    L.rt_dp_reset.argtypes = [vp]
+    L.rt_dp_get_accum.argtypes = [vp, C.POINTER(C.c_float * 3)]
+    L.rt_dp_set_accum.argtypes = [vp, C.POINTER(C.c_float * 3)]
+    L.rt_dp_eval_bundles.argtypes = [vp, vp, vp, C.c_uint64]
+    L.rt_dp_set_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.rt_dp_last_error.restype = C.c_char_p
+    L.rt_dp_version.restype = C.c_char_p
+    for name in EXPORTS:
+        if name not in ("rt_dp_destroy", "rt_dp_last_error", "rt_dp_version"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != OK:
+        raise RtDpError(rc, load().rt_dp_last_error().decode())
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x, kinds):
+    """Pointer of a numpy array (host) or torch tensor (device); records which in kinds."""
+    if x is None:
+        return None
+    if _is_torch(x):
+        if not x.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        kinds.add("cuda" if x.is_cuda else "host")
+        return x.data_ptr()
+    if not isinstance(x, np.ndarray) or not x.flags["C_CONTIGUOUS"]:
+        raise ValueError("array must be a C-contiguous numpy array or a contiguous torch tensor")
+    kinds.add("host")
+    return x.ctypes.data
+
+
+class Batch:
+    """Builder for one rt_dp_op_batch / rt_dp_result_batch pair.  Keeps every array alive."""
+
+    def __init__(self):
+        self.ob = OpBatch()
+        self.rb = ResultBatch()
+        self.ob.struct_size = C.sizeof(OpBatch)
+        self.rb.struct_size = C.sizeof(ResultBatch)
+        self._keep = []
+        self._kinds = set()
+
+    def _p(self, x):
+        self._keep.append(x)
+        return _ptr(x, self._kinds)
+
+    def set_box(self, fields, tmin, flags, n=None):
+        """fields: 34 arrays in BOX_FIELDS order; tmin: 4 output arrays; flags: uint32 output."""
+        assert len(fields) == 34 and len(tmin) == 4
+        b = self.ob.box
+        for a in range(3):
+            b.org[a] = self._p(fields[a])
+            b.dir[a] = self._p(fields[3 + a])
+            b.inv[a] = self._p(fields[6 + a])
+        b.extent = self._p(fields[9])
+        for bi in range(4):
+            for f in range(6):
+                b.aabb[bi][f] = self._p(fields[10 + 6 * bi + f])
+        for k in range(4):
+            self.rb.box.tmin_out[k] = self._p(tmin[k])
+        self.rb.box.flags = self._p(flags)
+        self.ob.n[OP_QUADBOX] = int(fields[0].shape[0]) if n is None else int(n)
+
+    def set_tri(self, fields, k, t_num, t_denom, hit, n=None):
+        """fields: 15 arrays in TRI_FIELDS order; k: packed kx|ky<<2|kz<<4."""
+        assert len(fields) == 15
+        t = self.ob.tri
+        for a in range(3):
+            t.org[a] = self._p(fields[a])
+            t.shear[a] = self._p(fields[3 + a])
+        for v in range(3):
+            for a in range(3):
+                t.vtx[v][a] = self._p(fields[6 + 3 * v + a])
+        t.k = self._p(k)
+        self.rb.tri.t_num = self._p(t_num)
+        self.rb.tri.t_denom = self._p(t_denom)
+        self.rb.tri.hit = self._p(hit)
+        self.ob.n[OP_TRIANGLE] = int(k.shape[0]) if n is None else int(n)
+
+    def set_euclid(self, a, b, ctl, acc, n=None):
+        self.ob.euc.a, self.ob.euc.b, self.ob.euc.ctl = self._p(a), self._p(b), self._p(ctl)
+        self.rb.euc.accumulator = self._p(acc)
+        self.ob.n[OP_EUCLIDEAN] = int(ctl.shape[0]) if n is None else int(n)
+
+    def set_angular(self, q, c, ctl, dot, norm, n=None):
+        self.ob.ang.a, self.ob.ang.b, self.ob.ang.ctl = self._p(q), self._p(c), self._p(ctl)
+        self.rb.ang.dot_product = self._p(dot)
+        self.rb.ang.norm = self._p(norm)
+        self.ob.n[OP_ANGULAR] = int(ctl.shape[0]) if n is None else int(n)
+
+    def finalize(self):
+        if len(self._kinds) > 1:
+            raise ValueError("a batch must not mix host and device arrays")
+        self.ob.flags = F_DEVICE_PTRS if "cuda" in self._kinds else 0
+        return self
+
+
+class Context:
+    """One datapath instance (rt_dp_ctx): owns the accumulator registers."""
+
+    def __init__(self, device=-1, support_euclidean=16, io_recorded_float=0, internal_recorded_float=1):
+        L = load()
+        cfg = Config(C.sizeof(Config), device, io_recorded_float, internal_recorded_float, support_euclidean, 0)
+        h = C.c_void_p()
+        _check(L.rt_dp_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rt_dp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def eval(self, batch):
+        batch.finalize()
+        _check(self._L.rt_dp_eval_ctx(self._h, C.byref(batch.ob), C.byref(batch.rb)))
+
+    def launch(self, batch, stream=None):
+        """Asynchronous launch on `stream` (int hipStream_t handle, e.g. torch's cuda_stream)."""
+        batch.finalize()
+        _check(self._L.rt_dp_launch(self._h, C.byref(batch.ob), C.byref(batch.rb), C.c_void_p(stream) if stream else None))
+
+    def synchronize(self):
+        _check(self._L.rt_dp_synchronize(self._h))
+
+    def reset(self):
+        _check(self._L.rt_dp_reset(self._h))
+
+    def get_accum(self):
+        a = (C.c_float * 3)()
+        _check(self._L.rt_dp_get_accum(self._h, C.byref(a)))
+        return np.array(list(a), np.float32)
+
+    def set_accum(self, acc):
+        a = (C.c_float * 3)(*[float(x) for x in acc])
+        _check(self._L.rt_dp_set_accum(self._h, C.byref(a)))
+
+    def set_tuning(self, ops_per_lane=0, nontemporal=0, vec_tile=0):
+        _check(self._L.rt_dp_set_tuning(self._h, ops_per_lane, nontemporal, vec_tile))
+
+    def eval_bundles(self, in_bundles):
+        """in_bundles: numpy structured array whose itemsize equals sizeof(rt_dp_input_bundle)
+        (84 uint32 words per record).  Returns a uint32 array [n, 21] of output bundles."""
+        raw = np.ascontiguousarray(in_bundles).view(np.uint32).reshape(-1, 84)
+        out = np.zeros((raw.shape[0], 21), np.uint32)
+        _check(self._L.rt_dp_eval_bundles(self._h, raw.ctypes.data, out.ctypes.data, raw.shape[0]))
+        return out
+
+
+def version():
+    return load().rt_dp_version().decode()
+
+
+def device_count():
+    return load().rt_dp_device_count()

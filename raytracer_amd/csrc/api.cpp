@@ -1,0 +1,501 @@
+// C ABI of librt_dp (see include/rt_dp.h): argument checking, contexts,
+// accumulator registers, host-pointer staging and the record-at-a-time path.
+#include "../../include/rt_dp.h"
+#include "kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <vector>
+
+using namespace rtdp;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(RT_DP_EHIP, "%s: %s", #expr, hipGetErrorString(e_));     \
+    } while (0)
+
+int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+constexpr uint64_t kMaxOps = 1ull << 40;
+
+}  // namespace
+
+struct rt_dp_ctx {
+    int device = 0;
+    bool extended = true;  // support_euclidean == Some(16)
+    hipStream_t stream = nullptr;
+    // accumulator registers live in HBM; two copies so that the workgroup that
+    // reads the incoming value never races the one that writes the outgoing one
+    float *d_state = nullptr;  // [2][4]: {euclid, dot, norm, pad}
+    int cur = 0;               // which copy is current
+    // grow-only staging for host-pointer batches
+    char *d_stage = nullptr;
+    size_t stage_bytes = 0;
+    Tuning tuning{0, 0, 0};
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess)) ok = true;
+    }
+    ~DeviceGuard() {
+        int now = -1;
+        if (prev >= 0 && hipGetDevice(&now) == hipSuccess && now != prev) (void)hipSetDevice(prev);
+    }
+};
+
+int check_batch(const rt_dp_op_batch *in, const rt_dp_result_batch *out) {
+    if (!in || !out) return fail(RT_DP_ENULL, "rt_dp: batch pointer is NULL");
+    if (in->struct_size != sizeof(rt_dp_op_batch)) return fail(RT_DP_EINVAL, "rt_dp_op_batch.struct_size is %u, expected %zu", in->struct_size, sizeof(rt_dp_op_batch));
+    if (out->struct_size != sizeof(rt_dp_result_batch)) return fail(RT_DP_EINVAL, "rt_dp_result_batch.struct_size is %u, expected %zu", out->struct_size, sizeof(rt_dp_result_batch));
+    if (in->flags & ~RT_DP_F_ALL_FLAGS) return fail(RT_DP_EINVAL, "unknown flag bits 0x%x", in->flags & ~RT_DP_F_ALL_FLAGS);
+    for (int op = 0; op < 4; ++op)
+        if (in->n[op] > kMaxOps) return fail(RT_DP_EINVAL, "n[%d] = %llu is not representable (limit 2^40)", op, (unsigned long long)in->n[op]);
+
+#define NEED(ptr, what)                                                                            \
+    do {                                                                                           \
+        if (!(ptr)) return fail(RT_DP_ENULL, "%s is NULL for a non-empty segment", what);          \
+        if (reinterpret_cast<uintptr_t>(ptr) & 3u) return fail(RT_DP_EALIGN, "%s is not 4-byte aligned", what); \
+    } while (0)
+
+    if (in->n[RT_DP_OP_TRIANGLE]) {
+        for (int a = 0; a < 3; ++a) { NEED(in->tri.org[a], "tri.org[]"); NEED(in->tri.shear[a], "tri.shear[]"); }
+        for (int v = 0; v < 3; ++v)
+            for (int a = 0; a < 3; ++a) NEED(in->tri.vtx[v][a], "tri.vtx[][]");
+        NEED(in->tri.k, "tri.k");
+        NEED(out->tri.t_num, "result tri.t_num");
+        NEED(out->tri.t_denom, "result tri.t_denom");
+        NEED(out->tri.hit, "result tri.hit");
+    }
+    if (in->n[RT_DP_OP_QUADBOX]) {
+        for (int a = 0; a < 3; ++a) { NEED(in->box.org[a], "box.org[]"); NEED(in->box.dir[a], "box.dir[]"); NEED(in->box.inv[a], "box.inv[]"); }
+        NEED(in->box.extent, "box.extent");
+        for (int b = 0; b < 4; ++b)
+            for (int f = 0; f < 6; ++f) NEED(in->box.aabb[b][f], "box.aabb[][]");
+        for (int k = 0; k < 4; ++k) NEED(out->box.tmin_out[k], "result box.tmin_out[]");
+        NEED(out->box.flags, "result box.flags");
+    }
+    if (in->n[RT_DP_OP_EUCLIDEAN]) {
+        NEED(in->euc.a, "euc.a"); NEED(in->euc.b, "euc.b"); NEED(in->euc.ctl, "euc.ctl");
+        NEED(out->euc.accumulator, "result euc.accumulator");
+    }
+    if (in->n[RT_DP_OP_ANGULAR]) {
+        NEED(in->ang.a, "ang.a"); NEED(in->ang.b, "ang.b"); NEED(in->ang.ctl, "ang.ctl");
+        NEED(out->ang.dot_product, "result ang.dot_product");
+        NEED(out->ang.norm, "result ang.norm");
+    }
+#undef NEED
+    return RT_DP_OK;
+}
+
+void fill_box(BoxArgs &a, const rt_dp_box_in &in, const rt_dp_box_out &out) {
+    int f = 0;
+    for (int i = 0; i < 3; ++i) a.in[f++] = in.org[i];
+    for (int i = 0; i < 3; ++i) a.in[f++] = in.dir[i];
+    for (int i = 0; i < 3; ++i) a.in[f++] = in.inv[i];
+    a.in[f++] = in.extent;
+    for (int b = 0; b < 4; ++b)
+        for (int k = 0; k < 6; ++k) a.in[f++] = in.aabb[b][k];
+    for (int k = 0; k < 4; ++k) a.tmin[k] = out.tmin_out[k];
+    a.flags = out.flags;
+}
+
+void fill_tri(TriArgs &a, const rt_dp_tri_in &in, const rt_dp_tri_out &out) {
+    int f = 0;
+    for (int i = 0; i < 3; ++i) a.in[f++] = in.org[i];
+    for (int i = 0; i < 3; ++i) a.in[f++] = in.shear[i];
+    for (int v = 0; v < 3; ++v)
+        for (int i = 0; i < 3; ++i) a.in[f++] = in.vtx[v][i];
+    a.k = in.k;
+    a.t_num = out.t_num;
+    a.t_denom = out.t_denom;
+    a.hit = out.hit;
+}
+
+// Enqueue the kernels of one batch whose arrays are all device pointers.
+int launch_device(rt_dp_ctx *ctx, const rt_dp_op_batch *in, const rt_dp_result_batch *out, hipStream_t s) {
+    const uint64_t n_tri = in->n[RT_DP_OP_TRIANGLE], n_box = in->n[RT_DP_OP_QUADBOX];
+    const uint64_t n_euc = in->n[RT_DP_OP_EUCLIDEAN], n_ang = in->n[RT_DP_OP_ANGULAR];
+    if (n_box) {
+        BoxArgs a;
+        fill_box(a, in->box, out->box);
+        HIP_TRY(launch_box(a, n_box, ctx->tuning, s));
+    }
+    if (n_tri) {
+        TriArgs a;
+        fill_tri(a, in->tri, out->tri);
+        HIP_TRY(launch_tri(a, n_tri, ctx->tuning, s));
+    }
+    if (!ctx->extended) {
+        // baseline datapath: opcodes 2/3 flow through untouched, outputs stay 0 and the
+        // accumulators are not part of the design (UnifiedDatapath.scala:224, :247)
+        if (n_euc) HIP_TRY(hipMemsetAsync(out->euc.accumulator, 0, n_euc * sizeof(float), s));
+        if (n_ang) {
+            HIP_TRY(hipMemsetAsync(out->ang.dot_product, 0, n_ang * sizeof(float), s));
+            HIP_TRY(hipMemsetAsync(out->ang.norm, 0, n_ang * sizeof(float), s));
+        }
+        return RT_DP_OK;
+    }
+    if (n_euc || n_ang) {
+        if (n_euc && ((reinterpret_cast<uintptr_t>(in->euc.a) | reinterpret_cast<uintptr_t>(in->euc.b)) & 15u))
+            return fail(RT_DP_EALIGN, "euc.a / euc.b must be 16-byte aligned device pointers");
+        if (n_ang && ((reinterpret_cast<uintptr_t>(in->ang.a) | reinterpret_cast<uintptr_t>(in->ang.b)) & 15u))
+            return fail(RT_DP_EALIGN, "ang.a / ang.b must be 16-byte aligned device pointers");
+        float *cur = ctx->d_state + 4 * ctx->cur, *nxt = ctx->d_state + 4 * (ctx->cur ^ 1);
+        // registers of an opcode without beats in this batch are carried over unchanged
+        HIP_TRY(hipMemcpyAsync(nxt, cur, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (n_euc) {
+            VecArgs a{in->euc.a, in->euc.b, in->euc.ctl, out->euc.accumulator, nullptr, cur + 0, nxt + 0};
+            HIP_TRY(launch_euclid(a, n_euc, ctx->tuning, s));
+        }
+        if (n_ang) {
+            VecArgs a{in->ang.a, in->ang.b, in->ang.ctl, out->ang.dot_product, out->ang.norm, cur + 1, nxt + 1};
+            HIP_TRY(launch_angular(a, n_ang, ctx->tuning, s));
+        }
+        ctx->cur ^= 1;
+    }
+    return RT_DP_OK;
+}
+
+struct Span { const void *src; void *dst_host; size_t bytes; size_t off; };
+
+size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
+
+// Host-pointer batch: stage through the context's device buffer.
+int eval_host(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *out) {
+    std::vector<Span> ins, outs;
+    size_t total = 0;
+    rt_dp_op_batch din = *in;
+    rt_dp_result_batch dout = *out;
+    din.flags |= RT_DP_F_DEVICE_PTRS;
+
+    auto add_in = [&](const void *host, size_t bytes) -> size_t { ins.push_back({host, nullptr, bytes, total}); size_t o = total; total += align_up(bytes); return o; };
+    auto add_out = [&](void *host, size_t bytes) -> size_t { outs.push_back({nullptr, host, bytes, total}); size_t o = total; total += align_up(bytes); return o; };
+
+    std::vector<std::pair<const void **, size_t>> fix_in;  // (field address, offset)
+    std::vector<std::pair<void **, size_t>> fix_out;
+#define IN_ARR(field, count, elt) fix_in.push_back({reinterpret_cast<const void **>(&(field)), add_in((field), (size_t)(count) * (elt))})
+#define OUT_ARR(field, count, elt) fix_out.push_back({reinterpret_cast<void **>(&(field)), add_out((field), (size_t)(count) * (elt))})
+
+    const uint64_t n_tri = in->n[RT_DP_OP_TRIANGLE], n_box = in->n[RT_DP_OP_QUADBOX];
+    const uint64_t n_euc = in->n[RT_DP_OP_EUCLIDEAN], n_ang = in->n[RT_DP_OP_ANGULAR];
+    if (n_tri) {
+        for (int a = 0; a < 3; ++a) { IN_ARR(din.tri.org[a], n_tri, 4); IN_ARR(din.tri.shear[a], n_tri, 4); }
+        for (int v = 0; v < 3; ++v)
+            for (int a = 0; a < 3; ++a) IN_ARR(din.tri.vtx[v][a], n_tri, 4);
+        IN_ARR(din.tri.k, n_tri, 4);
+        OUT_ARR(dout.tri.t_num, n_tri, 4); OUT_ARR(dout.tri.t_denom, n_tri, 4); OUT_ARR(dout.tri.hit, n_tri, 4);
+    }
+    if (n_box) {
+        for (int a = 0; a < 3; ++a) { IN_ARR(din.box.org[a], n_box, 4); IN_ARR(din.box.dir[a], n_box, 4); IN_ARR(din.box.inv[a], n_box, 4); }
+        IN_ARR(din.box.extent, n_box, 4);
+        for (int b = 0; b < 4; ++b)
+            for (int f = 0; f < 6; ++f) IN_ARR(din.box.aabb[b][f], n_box, 4);
+        for (int k = 0; k < 4; ++k) OUT_ARR(dout.box.tmin_out[k], n_box, 4);
+        OUT_ARR(dout.box.flags, n_box, 4);
+    }
+    if (n_euc) {
+        IN_ARR(din.euc.a, n_euc * 16, 4); IN_ARR(din.euc.b, n_euc * 16, 4); IN_ARR(din.euc.ctl, n_euc, 4);
+        OUT_ARR(dout.euc.accumulator, n_euc, 4);
+    }
+    if (n_ang) {
+        IN_ARR(din.ang.a, n_ang * 8, 4); IN_ARR(din.ang.b, n_ang * 8, 4); IN_ARR(din.ang.ctl, n_ang, 4);
+        OUT_ARR(dout.ang.dot_product, n_ang, 4); OUT_ARR(dout.ang.norm, n_ang, 4);
+    }
+#undef IN_ARR
+#undef OUT_ARR
+    if (total == 0) return RT_DP_OK;
+
+    if (total > ctx->stage_bytes) {
+        if (ctx->d_stage) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(ctx->d_stage)); ctx->d_stage = nullptr; ctx->stage_bytes = 0; }
+        size_t want = total + total / 4;
+        hipError_t e = hipMalloc(&ctx->d_stage, want);
+        if (e != hipSuccess) return fail(RT_DP_ENOMEM, "hipMalloc(%zu) for staging failed: %s", want, hipGetErrorString(e));
+        ctx->stage_bytes = want;
+    }
+    for (auto &f : fix_in) *f.first = ctx->d_stage + f.second;
+    for (auto &f : fix_out) *f.first = ctx->d_stage + f.second;
+    for (auto &s : ins) HIP_TRY(hipMemcpyAsync(ctx->d_stage + s.off, s.src, s.bytes, hipMemcpyHostToDevice, ctx->stream));
+    int rc = launch_device(ctx, &din, &dout, ctx->stream);
+    if (rc != RT_DP_OK) return rc;
+    for (auto &s : outs) HIP_TRY(hipMemcpyAsync(s.dst_host, ctx->d_stage + s.off, s.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_DP_OK;
+}
+
+thread_local rt_dp_ctx *g_default_ctx = nullptr;
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_dp_last_error(void) { return g_err; }
+
+const char *rt_dp_version(void) { return "rt_dp 0.1 (gfx950)"; }
+
+int rt_dp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rt_dp_create(const rt_dp_config *cfg, rt_dp_ctx **out) {
+    if (!out) return fail(RT_DP_ENULL, "rt_dp_create: out is NULL");
+    *out = nullptr;
+    rt_dp_config c{sizeof(rt_dp_config), -1, 0, 1, 16, 0};
+    if (cfg) {
+        if (cfg->struct_size != sizeof(rt_dp_config)) return fail(RT_DP_EINVAL, "rt_dp_config.struct_size is %u, expected %zu", cfg->struct_size, sizeof(rt_dp_config));
+        c = *cfg;
+    }
+    // elaboration-time asserts of the RTL (UnifiedDatapath.scala:36-47)
+    if (c.io_recorded_float != 0) return fail(RT_DP_EINVAL, "we don't support recorded-format Input/Output");
+    if (c.internal_recorded_float != 1) return fail(RT_DP_EINVAL, "we don't support standard-format intermediates");
+    if (c.support_euclidean != 0 && c.support_euclidean != 16)
+        return fail(RT_DP_EINVAL, "raytracer currently only support processing 16-element vector pairs for euclidean distance calculation");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RT_DP_ENODEV, "no HIP device available");
+    int dev = c.device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return fail(RT_DP_ENODEV, "hipGetDevice failed");
+    if (dev >= ndev) return fail(RT_DP_ENODEV, "device %d out of range (%d devices)", dev, ndev);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RT_DP_ENODEV, "device %d is %s; librt_dp carries gfx950 code only", dev, prop.gcnArchName);
+
+    DeviceGuard guard(dev);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", dev);
+    rt_dp_ctx *ctx = new (std::nothrow) rt_dp_ctx;
+    if (!ctx) return fail(RT_DP_ENOMEM, "out of host memory");
+    ctx->device = dev;
+    ctx->extended = (c.support_euclidean == 16);
+    ctx->tuning.ops_per_lane = env_int("RT_DP_OPS_PER_LANE", 0);
+    ctx->tuning.nontemporal = env_int("RT_DP_NONTEMPORAL", 0);
+    ctx->tuning.vec_tile = env_int("RT_DP_VEC_TILE", 0);
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_state, 8 * sizeof(float));
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_state, 0, 8 * sizeof(float), ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        int rc = fail(RT_DP_EHIP, "context set-up failed: %s", hipGetErrorString(e));
+        rt_dp_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return RT_DP_OK;
+}
+
+void rt_dp_destroy(rt_dp_ctx *ctx) {
+    if (!ctx) return;
+    DeviceGuard guard(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->d_state) (void)hipFree(ctx->d_state);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (g_default_ctx == ctx) g_default_ctx = nullptr;
+    delete ctx;
+}
+
+int rt_dp_launch(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *out, void *hip_stream) {
+    if (!ctx) return fail(RT_DP_ENULL, "rt_dp_launch: ctx is NULL");
+    int rc = check_batch(in, out);
+    if (rc != RT_DP_OK) return rc;
+    if (!(in->flags & RT_DP_F_DEVICE_PTRS)) return fail(RT_DP_EINVAL, "rt_dp_launch needs RT_DP_F_DEVICE_PTRS; use rt_dp_eval_ctx for host arrays");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
+    return launch_device(ctx, in, out, hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream);
+}
+
+int rt_dp_synchronize(rt_dp_ctx *ctx) {
+    if (!ctx) return fail(RT_DP_ENULL, "rt_dp_synchronize: ctx is NULL");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_DP_OK;
+}
+
+int rt_dp_eval_ctx(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *out) {
+    if (!ctx) return fail(RT_DP_ENULL, "rt_dp_eval_ctx: ctx is NULL");
+    int rc = check_batch(in, out);
+    if (rc != RT_DP_OK) return rc;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
+    if (in->flags & RT_DP_F_DEVICE_PTRS) {
+        rc = launch_device(ctx, in, out, ctx->stream);
+        if (rc != RT_DP_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return RT_DP_OK;
+    }
+    return eval_host(ctx, in, out);
+}
+
+int rt_dp_eval(const rt_dp_op_batch *in, rt_dp_result_batch *out) {
+    if (!g_default_ctx) {
+        int rc = rt_dp_create(nullptr, &g_default_ctx);
+        if (rc != RT_DP_OK) return rc;
+    }
+    return rt_dp_eval_ctx(g_default_ctx, in, out);
+}
+
+int rt_dp_reset(rt_dp_ctx *ctx) {
+    const float z[3] = {0.0f, 0.0f, 0.0f};
+    return rt_dp_set_accum(ctx, z);
+}
+
+int rt_dp_get_accum(rt_dp_ctx *ctx, float acc[3]) {
+    if (!ctx || !acc) return fail(RT_DP_ENULL, "rt_dp_get_accum: NULL argument");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(acc, ctx->d_state + 4 * ctx->cur, 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_DP_OK;
+}
+
+int rt_dp_set_accum(rt_dp_ctx *ctx, const float acc[3]) {
+    if (!ctx || !acc) return fail(RT_DP_ENULL, "rt_dp_set_accum: NULL argument");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const float v[4] = {acc[0], acc[1], acc[2], 0.0f};
+    HIP_TRY(hipMemcpy(ctx->d_state + 4 * ctx->cur, v, sizeof v, hipMemcpyHostToDevice));
+    return RT_DP_OK;
+}
+
+int rt_dp_set_tuning(rt_dp_ctx *ctx, int ops_per_lane, int nontemporal, int vec_tile) {
+    if (!ctx) return fail(RT_DP_ENULL, "rt_dp_set_tuning: ctx is NULL");
+    if (ops_per_lane != 0 && ops_per_lane != 1 && ops_per_lane != 2 && ops_per_lane != 4) return fail(RT_DP_EINVAL, "ops_per_lane must be 0, 1, 2 or 4");
+    if (vec_tile < 0 || (vec_tile % 256) != 0) return fail(RT_DP_EINVAL, "vec_tile must be a non-negative multiple of 256");
+    ctx->tuning.ops_per_lane = ops_per_lane;
+    ctx->tuning.nontemporal = nontemporal ? 1 : 0;
+    ctx->tuning.vec_tile = vec_tile;
+    return RT_DP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Record-at-a-time stream: partition by opcode (stable), evaluate, scatter.
+int rt_dp_eval_bundles(rt_dp_ctx *ctx, const rt_dp_input_bundle *in, rt_dp_output_bundle *out, uint64_t n) {
+    if (!ctx) return fail(RT_DP_ENULL, "rt_dp_eval_bundles: ctx is NULL");
+    if (n == 0) return RT_DP_OK;
+    if (!in || !out) return fail(RT_DP_ENULL, "rt_dp_eval_bundles: in/out is NULL");
+    if (n > kMaxOps) return fail(RT_DP_EINVAL, "n = %llu is not representable (limit 2^40)", (unsigned long long)n);
+
+    std::vector<uint64_t> idx[4];
+    for (uint64_t i = 0; i < n; ++i) {
+        if (in[i].opcode > 3u) return fail(RT_DP_EOPCODE, "record %llu has opcode %u; the RTL's opcode field is 2 bits wide", (unsigned long long)i, in[i].opcode);
+        idx[in[i].opcode].push_back(i);
+    }
+    const uint64_t nt = idx[0].size(), nb = idx[1].size(), ne = idx[2].size(), na = idx[3].size();
+    auto F = [](uint32_t bits) { float f; memcpy(&f, &bits, 4); return f; };
+    auto B = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+
+    // SoA images
+    std::vector<float> tri_in[kTriFields], box_in[kBoxFields], box_t[4], tri_num(nt), tri_den(nt);
+    std::vector<uint32_t> tri_k(nt), tri_hit(nt), box_flags(nb), euc_ctl(ne), ang_ctl(na);
+    std::vector<float> euc_a(ne * 16), euc_b(ne * 16), euc_o(ne), ang_a(na * 8), ang_b(na * 8), ang_d(na), ang_n(na);
+    for (auto &v : tri_in) v.resize(nt);
+    for (auto &v : box_in) v.resize(nb);
+    for (auto &v : box_t) v.resize(nb);
+
+    for (uint64_t j = 0; j < nt; ++j) {
+        const rt_dp_input_bundle &r = in[idx[0][j]];
+        const uint32_t w[kTriFields] = {r.ray.origin.x, r.ray.origin.y, r.ray.origin.z, r.ray.shear.x, r.ray.shear.y, r.ray.shear.z,
+                                        r.triangle.A.x, r.triangle.A.y, r.triangle.A.z, r.triangle.B.x, r.triangle.B.y, r.triangle.B.z,
+                                        r.triangle.C.x, r.triangle.C.y, r.triangle.C.z};
+        for (int f = 0; f < kTriFields; ++f) tri_in[f][j] = F(w[f]);
+        tri_k[j] = (r.ray.kx & 3u) | ((r.ray.ky & 3u) << 2) | ((r.ray.kz & 3u) << 4);
+    }
+    for (uint64_t j = 0; j < nb; ++j) {
+        const rt_dp_input_bundle &r = in[idx[1][j]];
+        uint32_t w[kBoxFields] = {r.ray.origin.x, r.ray.origin.y, r.ray.origin.z, r.ray.dir.x, r.ray.dir.y, r.ray.dir.z,
+                                  r.ray.inv.x, r.ray.inv.y, r.ray.inv.z, r.ray.extent};
+        for (int b = 0; b < 4; ++b) {
+            const rt_dp_aabb &bb = r.aabb[b];
+            const uint32_t q[6] = {bb.x_min, bb.y_min, bb.z_min, bb.x_max, bb.y_max, bb.z_max};
+            for (int f = 0; f < 6; ++f) w[10 + 6 * b + f] = q[f];
+        }
+        for (int f = 0; f < kBoxFields; ++f) box_in[f][j] = F(w[f]);
+    }
+    for (uint64_t j = 0; j < ne; ++j) {
+        const rt_dp_input_bundle &r = in[idx[2][j]];
+        for (int e = 0; e < 16; ++e) { euc_a[j * 16 + e] = F(r.euclidean_a[e]); euc_b[j * 16 + e] = F(r.euclidean_b[e]); }
+        euc_ctl[j] = RT_DP_CTL(r.euclidean_mask & 0xFFFFu, r.euclidean_reset_accum & 1u);
+    }
+    for (uint64_t j = 0; j < na; ++j) {
+        const rt_dp_input_bundle &r = in[idx[3][j]];
+        for (int e = 0; e < 8; ++e) { ang_a[j * 8 + e] = F(r.euclidean_a[e]); ang_b[j * 8 + e] = F(r.euclidean_b[e]); }
+        ang_ctl[j] = RT_DP_CTL(r.euclidean_mask & 0xFFFFu, r.euclidean_reset_accum & 1u);
+    }
+
+    rt_dp_op_batch ob;
+    rt_dp_result_batch rb;
+    memset(&ob, 0, sizeof ob);
+    memset(&rb, 0, sizeof rb);
+    ob.struct_size = sizeof ob;
+    rb.struct_size = sizeof rb;
+    ob.n[0] = nt; ob.n[1] = nb; ob.n[2] = ne; ob.n[3] = na;
+    for (int a = 0; a < 3; ++a) { ob.tri.org[a] = tri_in[a].data(); ob.tri.shear[a] = tri_in[3 + a].data(); }
+    for (int v = 0; v < 3; ++v)
+        for (int a = 0; a < 3; ++a) ob.tri.vtx[v][a] = tri_in[6 + 3 * v + a].data();
+    ob.tri.k = tri_k.data();
+    rb.tri.t_num = tri_num.data(); rb.tri.t_denom = tri_den.data(); rb.tri.hit = tri_hit.data();
+    for (int a = 0; a < 3; ++a) { ob.box.org[a] = box_in[a].data(); ob.box.dir[a] = box_in[3 + a].data(); ob.box.inv[a] = box_in[6 + a].data(); }
+    ob.box.extent = box_in[9].data();
+    for (int b = 0; b < 4; ++b)
+        for (int f = 0; f < 6; ++f) ob.box.aabb[b][f] = box_in[10 + 6 * b + f].data();
+    for (int k = 0; k < 4; ++k) rb.box.tmin_out[k] = box_t[k].data();
+    rb.box.flags = box_flags.data();
+    ob.euc.a = euc_a.data(); ob.euc.b = euc_b.data(); ob.euc.ctl = euc_ctl.data(); rb.euc.accumulator = euc_o.data();
+    ob.ang.a = ang_a.data(); ob.ang.b = ang_b.data(); ob.ang.ctl = ang_ctl.data(); rb.ang.dot_product = ang_d.data(); rb.ang.norm = ang_n.data();
+
+    int rc = rt_dp_eval_ctx(ctx, &ob, &rb);
+    if (rc != RT_DP_OK) return rc;
+
+    for (uint64_t i = 0; i < n; ++i) {
+        memset(&out[i], 0, sizeof out[i]);
+        out[i].opcode = in[i].opcode;
+        if (ctx->extended) {
+            out[i].euclidean_reset_accum = in[i].euclidean_reset_accum & 1u;
+            out[i].angular_reset_accum = in[i].euclidean_reset_accum & 1u;
+        }
+    }
+    for (uint64_t j = 0; j < nt; ++j) {
+        rt_dp_output_bundle &o = out[idx[0][j]];
+        o.t_num = B(tri_num[j]); o.t_denom = B(tri_den[j]); o.triangle_hit = tri_hit[j];
+    }
+    for (uint64_t j = 0; j < nb; ++j) {
+        rt_dp_output_bundle &o = out[idx[1][j]];
+        for (int k = 0; k < 4; ++k) {
+            o.tmin_out[k] = B(box_t[k][j]);
+            o.isIntersect[k] = RT_DP_BOX_ISECT(box_flags[j], k);
+            o.boxIndex[k] = RT_DP_BOX_INDEX(box_flags[j], k);
+        }
+    }
+    if (ctx->extended) {
+        for (uint64_t j = 0; j < ne; ++j) out[idx[2][j]].euclidean_accumulator = B(euc_o[j]);
+        for (uint64_t j = 0; j < na; ++j) { out[idx[3][j]].angular_dot_product = B(ang_d[j]); out[idx[3][j]].angular_norm = B(ang_n[j]); }
+    }
+    return RT_DP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,49 @@
+// Device-side entry points of librt_dp: one launcher per datapath opcode.
+// All pointers are device pointers of the current GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtdp {
+
+constexpr int kBoxFields = 34;  // org xyz, dir xyz, inv xyz, extent, 4 x (x_min,y_min,z_min,x_max,y_max,z_max)
+constexpr int kTriFields = 15;  // org xyz, shear xyz, A xyz, B xyz, C xyz
+
+struct BoxArgs {
+    const float *in[kBoxFields];
+    float *tmin[4];
+    uint32_t *flags;
+};
+
+struct TriArgs {
+    const float *in[kTriFields];
+    const uint32_t *k;
+    float *t_num;
+    float *t_denom;
+    uint32_t *hit;
+};
+
+struct VecArgs {
+    const float *a;       // [n][16] (Euclidean) or [n][8] (angular query)
+    const float *b;       // [n][16] (Euclidean) or [n][8] (angular candidate)
+    const uint32_t *ctl;  // mask | reset << 16
+    float *out0;          // euclidean_accumulator / angular_dot_product
+    float *out1;          // unused / angular_norm
+    const float *state_in;  // accumulator register(s) entering beat 0: [1] Euclidean, [2] angular
+    float *state_out;       // accumulator register(s) after the last beat
+};
+
+// Tunables, settable per launch (0 = library default).  Exposed so the bench
+// harness can A/B kernel shapes in one process.
+struct Tuning {
+    int ops_per_lane;  // box / triangle: 1, 2 or 4 consecutive ops per lane
+    int nontemporal;   // 1: streaming loads/stores carry the nt cache hint
+    int vec_tile;      // Euclidean / angular: nominal beats per workgroup (multiple of 256)
+};
+
+hipError_t launch_box(const BoxArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
+hipError_t launch_tri(const TriArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
+hipError_t launch_euclid(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
+hipError_t launch_angular(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
+
+}  // namespace rtdp

@@ -1,0 +1,466 @@
+// HIP kernels for the four UnifiedDatapath opcodes, written for gfx950 (CDNA4):
+// 64-lane wavefronts, one lane owns whole ops (box, triangle) or a quarter /
+// half of a beat (Euclidean / angular), 128-bit coalesced global accesses.
+//
+// Numerics contract (what makes the results bit-identical to the RTL's
+// HardFloat units; reference external/hardfloat/src/main/scala/AddRecFN.scala,
+// MulRecFN.scala, CompareRecFN.scala, RoundAnyRawFNToRecFN.scala):
+//   * every add / sub / mul is a separate IEEE-754 binary32 RNE VALU op:
+//     this file is built with -ffp-contract=off and carries the pragma below,
+//     so no v_fma / v_mad / v_mac is ever formed;
+//   * f32 subnormals are kept (the default FP mode of a HIP kernel on gfx9);
+//   * min / max are NOT v_min / v_max: the RTL's compare-select keeps the first
+//     operand when a >= b and yields the second one otherwise, also for NaN
+//     (reference src/main/scala/raytracer_datapath/RecFNCompareSelect.scala:41-50);
+//   * a NaN that reaches an output is rewritten to the RTL's canonical
+//     0x7FC00000 (RoundAnyRawFNToRecFN.scala:249,277,280).
+//
+// File:line citations below are relative to the reference's
+// src/main/scala/raytracer_datapath/UnifiedDatapath.scala unless stated.
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace rtdp {
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+
+template <int V> struct Pack;
+template <> struct Pack<1> { using F = float; using U = uint32_t; };
+template <> struct Pack<2> { using F = f2v;   using U = u2v; };
+template <> struct Pack<4> { using F = f4v;   using U = u4v; };
+
+template <int V> __device__ __forceinline__ float lane_get(const typename Pack<V>::F &v, int i) { return v[i]; }
+template <> __device__ __forceinline__ float lane_get<1>(const float &v, int) { return v; }
+template <int V> __device__ __forceinline__ void lane_set(typename Pack<V>::F &v, int i, float x) { v[i] = x; }
+template <> __device__ __forceinline__ void lane_set<1>(float &v, int, float x) { v = x; }
+template <int V> __device__ __forceinline__ uint32_t lane_getu(const typename Pack<V>::U &v, int i) { return v[i]; }
+template <> __device__ __forceinline__ uint32_t lane_getu<1>(const uint32_t &v, int) { return v; }
+template <int V> __device__ __forceinline__ void lane_setu(typename Pack<V>::U &v, int i, uint32_t x) { v[i] = x; }
+template <> __device__ __forceinline__ void lane_setu<1>(uint32_t &v, int, uint32_t x) { v = x; }
+
+template <typename T, bool NT> __device__ __forceinline__ T ld(const void *p) {
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const T *>(p));
+    return *reinterpret_cast<const T *>(p);
+}
+template <typename T, bool NT> __device__ __forceinline__ void st(void *p, T v) {
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<T *>(p));
+    else *reinterpret_cast<T *>(p) = v;
+}
+
+__device__ __forceinline__ float canon_nan(float f) { return (f != f) ? __uint_as_float(0x7FC00000u) : f; }
+
+// M / m of the RTL's compare-and-swap: keep when p >= q (CompareAndSwapRecFN.scala:39-46).
+__device__ __forceinline__ float sel_hi(float p, float q) { return (p >= q) ? p : q; }
+__device__ __forceinline__ float sel_lo(float p, float q) { return (p >= q) ? q : p; }
+
+// ------------------------------------------------------------------ Quadbox
+// r[34] in BoxArgs order.  Stage 2 :167-220, stage 3 :346-398, stage 4 :534-631,
+// stage 10 :1117-1132 (sort network QuadSortRecFNWithIndex.scala:27-33, reversed).
+__device__ __forceinline__ void box_one(const float (&r)[kBoxFields], float (&t)[4], uint32_t &flags) {
+    const float ext = r[9];
+    bool keep[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) keep[a] = (r[3 + a] >= 0.0f);  // dir == -0 keeps, dir NaN swaps (:568-594)
+
+    float key[4];
+    uint32_t pay[4];  // box index | hit << 2 travels with its key through the network
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        float tn[3], tx[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float lo = (r[10 + 6 * b + a] - r[a]) * r[6 + a];
+            const float hi = (r[13 + 6 * b + a] - r[a]) * r[6 + a];
+            tn[a] = keep[a] ? lo : hi;
+            tx[a] = keep[a] ? hi : lo;
+        }
+        // network element 0 of (x, y, z, +0) and element 3 of (x, y, z, extent) (:600-612)
+        const float tmin = sel_hi(sel_hi(tn[0], tn[2]), sel_hi(tn[1], 0.0f));
+        const float tmax = sel_lo(sel_lo(tx[0], tx[2]), sel_lo(tx[1], ext));
+        const bool hit = (tmin < tmax);                         // :618-623
+        key[b] = hit ? tmin : __uint_as_float(0x7F800000u);     // :626-629
+        pay[b] = (uint32_t)b | ((uint32_t)hit << 2);
+    }
+#define RTDP_CAS(i, j)                                              \
+    {                                                               \
+        const bool keep_ij = (key[i] >= key[j]);                    \
+        const float ki = keep_ij ? key[i] : key[j];                 \
+        const float kj = keep_ij ? key[j] : key[i];                 \
+        const uint32_t pi = keep_ij ? pay[i] : pay[j];              \
+        const uint32_t pj = keep_ij ? pay[j] : pay[i];              \
+        key[i] = ki; key[j] = kj; pay[i] = pi; pay[j] = pj;         \
+    }
+    RTDP_CAS(0, 2) RTDP_CAS(1, 3) RTDP_CAS(0, 1) RTDP_CAS(2, 3) RTDP_CAS(1, 2)
+#undef RTDP_CAS
+    uint32_t f = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // network output is largest-first; the RTL reverses it (:1120-1130)
+        t[k] = key[3 - k];
+        f |= ((pay[3 - k] >> 2) & 1u) << k;
+        f |= (pay[3 - k] & 3u) << (4 + 2 * k);
+    }
+    flags = f;
+}
+
+template <int V, bool NT>
+__global__ __launch_bounds__(256) void k_box(BoxArgs args, uint64_t first, uint64_t groups) {
+    using F = typename Pack<V>::F;
+    using U = typename Pack<V>::U;
+    const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (g >= groups) return;
+    const uint64_t i0 = first + g * V;
+
+    F x[kBoxFields];
+#pragma unroll
+    for (int f = 0; f < kBoxFields; ++f) x[f] = ld<F, NT>(args.in[f] + i0);
+
+    F to[4];
+    U fo;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        float r[kBoxFields], t[4];
+        uint32_t fl;
+#pragma unroll
+        for (int f = 0; f < kBoxFields; ++f) r[f] = lane_get<V>(x[f], v);
+        box_one(r, t, fl);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lane_set<V>(to[k], v, t[k]);
+        lane_setu<V>(fo, v, fl);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st<F, NT>(args.tmin[k] + i0, to[k]);
+    st<U, NT>(args.flags + i0, fo);
+}
+
+// ----------------------------------------------------------------- Triangle
+// CompareRecFN's lt against +0 (external/hardfloat/src/main/scala/CompareRecFN.scala:65-70):
+// true exactly for the patterns 0x80000001 .. 0xFF800000 (negative, not -0, not NaN).
+// Done on the integer image so that the four tests of stage 10 stay four
+// independent predicates (a float formulation gets merged into v_min3_f32).
+__device__ __forceinline__ bool lt_zero(float x) { return (__float_as_uint(x) - 0x80000001u) <= 0x7F7FFFFFu; }
+
+__device__ __forceinline__ float at3(float x, float y, float z, uint32_t k) {  // Float3.at, IOSpec.scala:41-51
+    return (k == 0u) ? x : ((k == 1u) ? y : z);
+}
+
+// r[15] in TriArgs order.  Stage 2 :118-166, 3 :293-345, 4 :486-533, 5 :688-726,
+// 6 :753-781, 7 :844-871, 8 :898-913, 9 :990-1005, 10 :1087-1116.
+__device__ __forceinline__ void tri_one(const float (&r)[kTriFields], uint32_t kw, float &t_num, float &t_denom, uint32_t &hit) {
+    const uint32_t kx = kw & 3u, ky = (kw >> 2) & 3u, kz = (kw >> 4) & 3u;
+    const float nsx = -r[3], nsy = -r[4], sz = r[5];  // sign flip of shear.x / shear.y is a bit flip (FNHelpers.scala:12-19)
+    float X[3], Y[3], Z[3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        const float px = r[6 + 3 * v] - r[0];
+        const float py = r[7 + 3 * v] - r[1];
+        const float pz = r[8 + 3 * v] - r[2];
+        const float pk = at3(px, py, pz, kz);
+        const float mx = nsx * pk;
+        const float my = nsy * pk;
+        Z[v] = sz * pk;
+        X[v] = at3(px, py, pz, kx) + mx;
+        Y[v] = at3(px, py, pz, ky) + my;
+    }
+    // A = 0, B = 1, C = 2
+    const float U = X[2] * Y[1] - Y[2] * X[1];
+    const float V = X[0] * Y[2] - Y[0] * X[2];
+    const float W = X[1] * Y[0] - Y[1] * X[0];
+    const float uaz = U * Z[0], vbz = V * Z[1], wcz = W * Z[2];
+    const float den = (U + V) + W;
+    const float num = (uaz + vbz) + wcz;
+    // a NaN compares false everywhere, so it hits unless t_denom == +-0
+    hit = (!(lt_zero(U) || lt_zero(V) || lt_zero(W) || lt_zero(num)) && !(den == 0.0f)) ? 1u : 0u;
+    t_num = canon_nan(num);
+    t_denom = canon_nan(den);
+}
+
+template <int V, bool NT>
+__global__ __launch_bounds__(256) void k_tri(TriArgs args, uint64_t first, uint64_t groups) {
+    using F = typename Pack<V>::F;
+    using U = typename Pack<V>::U;
+    const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (g >= groups) return;
+    const uint64_t i0 = first + g * V;
+
+    F x[kTriFields];
+#pragma unroll
+    for (int f = 0; f < kTriFields; ++f) x[f] = ld<F, NT>(args.in[f] + i0);
+    const U kk = ld<U, NT>(args.k + i0);
+
+    F on, od;
+    U oh;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        float r[kTriFields], n, d;
+        uint32_t h;
+#pragma unroll
+        for (int f = 0; f < kTriFields; ++f) r[f] = lane_get<V>(x[f], v);
+        tri_one(r, lane_getu<V>(kk, v), n, d, h);
+        lane_set<V>(on, v, n);
+        lane_set<V>(od, v, d);
+        lane_setu<V>(oh, v, h);
+    }
+    st<F, NT>(args.t_num + i0, on);
+    st<F, NT>(args.t_denom + i0, od);
+    st<U, NT>(args.hit + i0, oh);
+}
+
+// ------------------------------------------------- Euclidean / angular beats
+// A beat's 16 (8) element pairs are spread over 4 (2) adjacent lanes, four
+// elements per lane, so one wave-instruction loads 1 KiB of contiguous vector
+// data.  The RTL's adder tree pairs element i with i+8, i+4, i+2, i+1
+// (:632-649, :783-803, :915-935, :1007-1027; angular: i+4, i+2, i+1, :650-676,
+// :804-832, :936-964): the first levels are lane-xor exchanges inside the quad
+// (DPP quad_perm, no LDS), the last two are in-lane adds.  IEEE addition is
+// commutative, so both partners of an exchange hold the same bits.
+//
+// The accumulator (:1133-1154, angular :1028-1064) is a strictly sequential
+// float sum over the beats of one vector pair, so it cannot be re-associated.
+// Each workgroup therefore owns whole vector pairs: its range starts at the
+// first pair boundary at or after blockIdx * tile and ends at the first pair
+// boundary at or after (blockIdx + 1) * tile.  Inside a 256-beat sub-tile the
+// per-beat tree sums go to LDS and one lane per vector pair walks its beats in
+// order.  A pair longer than a tile is handled entirely by the workgroup in
+// whose nominal range it starts.
+
+constexpr int kSub = 256;  // beats per sub-tile == threads per workgroup
+
+__device__ __forceinline__ float quad_xor1(float v) {  // quad_perm [1,0,3,2]
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor2(float v) {  // quad_perm [2,3,0,1]
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+
+// First pair boundary at or after `nominal` (a beat index whose predecessor
+// carries the reset bit), n if there is none.  Executed by one full wave.
+__device__ __forceinline__ uint64_t pair_boundary(const uint32_t *ctl, uint64_t nominal, uint64_t n, int lane) {
+    if (nominal == 0) return 0;
+    if (nominal >= n) return n;
+    for (uint64_t i0 = nominal;; i0 += 64) {  // terminates: indices >= n act as boundaries
+        const uint64_t i = i0 + lane;
+        const bool p = (i < n) ? (((ctl[i - 1] >> 16) & 1u) != 0u) : true;
+        const unsigned long long m = __ballot(p);
+        if (m) {
+            const uint64_t r = i0 + (uint64_t)(__ffsll((long long)m) - 1);
+            return r < n ? r : n;
+        }
+    }
+}
+
+template <bool EUC, bool NT>
+__global__ __launch_bounds__(256) void k_vec(VecArgs args, uint64_t n, uint32_t tile) {
+    constexpr int LPB = EUC ? 4 : 2;         // lanes per beat
+    constexpr int BPP = kSub / LPB;          // beats per pass
+    constexpr int PASSES = LPB;              // passes per sub-tile
+    constexpr int ROW = EUC ? 16 : 8;        // floats per beat and vector
+
+    __shared__ float s_sum0[kSub];
+    __shared__ float s_sum1[EUC ? 1 : kSub];
+    __shared__ uint32_t s_ctl[kSub];
+    __shared__ float s_out0[kSub];
+    __shared__ float s_out1[EUC ? 1 : kSub];
+    __shared__ uint64_t s_range[2];
+    __shared__ float s_carry[2][2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave < 2) {
+        const uint64_t r = pair_boundary(args.ctl, (uint64_t)(blockIdx.x + wave) * tile, n, lane);
+        if (lane == 0) s_range[wave] = r;
+    }
+    if (tid == 0) {
+        // only the workgroup that starts at beat 0 can inherit a running sum
+        s_carry[0][0] = (blockIdx.x == 0) ? args.state_in[0] : 0.0f;
+        s_carry[0][1] = (!EUC && blockIdx.x == 0) ? args.state_in[1] : 0.0f;
+    }
+    __syncthreads();
+    const uint64_t lo = s_range[0], hi = s_range[1];
+    if (lo >= hi) return;
+
+    const int part = tid % LPB;  // which four elements of the beat
+    int par = 0;
+    for (uint64_t base = lo; base < hi; base += kSub, par ^= 1) {
+        const int cnt = (hi - base < (uint64_t)kSub) ? (int)(hi - base) : kSub;
+
+        // phase 1: tree sums of this sub-tile's beats
+        f4v va[PASSES], vb[PASSES];
+        uint32_t vc[PASSES];
+#pragma unroll
+        for (int u = 0; u < PASSES; ++u) {
+            const int bl = u * BPP + tid / LPB;
+            if (bl < cnt) {
+                const uint64_t e = (base + bl) * ROW + part * 4;
+                va[u] = ld<f4v, NT>(args.a + e);
+                vb[u] = ld<f4v, NT>(args.b + e);
+                vc[u] = args.ctl[base + bl];
+            } else {
+                va[u] = (f4v)(0.0f); vb[u] = (f4v)(0.0f); vc[u] = 0u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PASSES; ++u) {
+            const int bl = u * BPP + tid / LPB;
+            const uint32_t mbits = vc[u] >> (part * 4);
+            float s0[4], s1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool on = (mbits >> j) & 1u;
+                if (EUC) {
+                    const float d = on ? (va[u][j] - vb[u][j]) : 0.0f;  // :221-245
+                    s0[j] = d * d;                                      // :399-419
+                } else {
+                    const float q = on ? va[u][j] : 0.0f;               // :246-268
+                    const float c = on ? vb[u][j] : 0.0f;
+                    s0[j] = q * c;                                      // :420-453
+                    s1[j] = c * c;
+                }
+            }
+            float r0, r1 = 0.0f;
+            if (EUC) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s0[j] = s0[j] + quad_xor2(s0[j]);  // i, i+8
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s0[j] = s0[j] + quad_xor1(s0[j]);  // i, i+4
+                r0 = (s0[0] + s0[2]) + (s0[1] + s0[3]);                        // i, i+2 then 0, 1
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s0[j] = s0[j] + quad_xor1(s0[j]); s1[j] = s1[j] + quad_xor1(s1[j]); }  // i, i+4
+                r0 = (s0[0] + s0[2]) + (s0[1] + s0[3]);
+                r1 = (s1[0] + s1[2]) + (s1[1] + s1[3]);
+            }
+            if (part == 0 && bl < cnt) {
+                s_sum0[bl] = r0;
+                if (!EUC) s_sum1[bl] = r1;
+                s_ctl[bl] = vc[u];
+            }
+        }
+        __syncthreads();
+
+        // phase 2: one lane per vector pair accumulates its beats in order
+        if (tid < cnt) {
+            const bool starts = (tid == 0) || (((s_ctl[tid - 1] >> 16) & 1u) != 0u);
+            if (starts) {
+                float acc0 = (tid == 0) ? s_carry[par][0] : 0.0f;
+                float acc1 = (tid == 0) ? s_carry[par][1] : 0.0f;
+                int i = tid;
+                bool rs;
+                do {
+                    const float o0 = acc0 + s_sum0[i];
+                    s_out0[i] = canon_nan(o0);
+                    rs = ((s_ctl[i] >> 16) & 1u) != 0u;
+                    acc0 = rs ? 0.0f : o0;
+                    if (!EUC) {
+                        const float o1 = acc1 + s_sum1[i];
+                        s_out1[i] = canon_nan(o1);
+                        acc1 = rs ? 0.0f : o1;
+                    }
+                    ++i;
+                } while (i < cnt && !rs);
+                if (i == cnt) {  // exactly one lane reaches the end of the sub-tile
+                    s_carry[par ^ 1][0] = acc0;
+                    s_carry[par ^ 1][1] = acc1;
+                }
+            }
+        }
+        __syncthreads();
+
+        // phase 3: coalesced result store
+        if (tid < cnt) {
+            st<float, NT>(args.out0 + base + tid, s_out0[tid]);
+            if (!EUC) st<float, NT>(args.out1 + base + tid, s_out1[tid]);
+        }
+    }
+    if (hi == n && tid == 0) {  // the workgroup that owns the last beat hands the registers on
+        args.state_out[0] = canon_nan(s_carry[par][0]);
+        if (!EUC) args.state_out[1] = canon_nan(s_carry[par][1]);
+    }
+}
+
+// ---------------------------------------------------------------- launchers
+
+static inline int min_align(const void *const *ptrs, int count) {
+    uintptr_t acc = 0;
+    for (int i = 0; i < count; ++i) acc |= reinterpret_cast<uintptr_t>(ptrs[i]);
+    if ((acc & 15u) == 0) return 16;
+    if ((acc & 7u) == 0) return 8;
+    return 4;
+}
+
+#define RTDP_LAUNCH_OPS(KERNEL, ARGS, N, V, NT, STREAM)                                               \
+    do {                                                                                              \
+        const uint64_t groups_ = (N) / (V);                                                           \
+        if (groups_) {                                                                                \
+            const uint64_t blocks_ = (groups_ + 255) / 256;                                           \
+            hipLaunchKernelGGL((KERNEL<V, NT>), dim3((unsigned)blocks_), dim3(256), 0, STREAM, ARGS,  \
+                               (uint64_t)0, groups_);                                                 \
+        }                                                                                             \
+        const uint64_t tail_ = (N) - groups_ * (V);                                                   \
+        if ((V) > 1 && tail_) {                                                                       \
+            hipLaunchKernelGGL((KERNEL<1, NT>), dim3(1), dim3(256), 0, STREAM, ARGS, groups_ * (V),   \
+                               tail_);                                                                \
+        }                                                                                             \
+    } while (0)
+
+template <bool NT> static void launch_box_v(const BoxArgs &a, uint64_t n, int v, hipStream_t s) {
+    if (v == 4) RTDP_LAUNCH_OPS(k_box, a, n, 4, NT, s);
+    else if (v == 2) RTDP_LAUNCH_OPS(k_box, a, n, 2, NT, s);
+    else RTDP_LAUNCH_OPS(k_box, a, n, 1, NT, s);
+}
+template <bool NT> static void launch_tri_v(const TriArgs &a, uint64_t n, int v, hipStream_t s) {
+    if (v == 4) RTDP_LAUNCH_OPS(k_tri, a, n, 4, NT, s);
+    else if (v == 2) RTDP_LAUNCH_OPS(k_tri, a, n, 2, NT, s);
+    else RTDP_LAUNCH_OPS(k_tri, a, n, 1, NT, s);
+}
+
+static int pick_v(int requested, int align_bytes, int dflt) {
+    int v = requested > 0 ? requested : dflt;
+    if (v != 1 && v != 2 && v != 4) v = dflt;
+    while (v * 4 > align_bytes) v >>= 1;
+    return v < 1 ? 1 : v;
+}
+
+hipError_t launch_box(const BoxArgs &args, uint64_t n, const Tuning &t, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const void *ptrs[kBoxFields + 5];
+    for (int i = 0; i < kBoxFields; ++i) ptrs[i] = args.in[i];
+    for (int i = 0; i < 4; ++i) ptrs[kBoxFields + i] = args.tmin[i];
+    ptrs[kBoxFields + 4] = args.flags;
+    const int v = pick_v(t.ops_per_lane, min_align(ptrs, kBoxFields + 5), 4);
+    if (t.nontemporal) launch_box_v<true>(args, n, v, stream);
+    else launch_box_v<false>(args, n, v, stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_tri(const TriArgs &args, uint64_t n, const Tuning &t, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const void *ptrs[kTriFields + 4];
+    for (int i = 0; i < kTriFields; ++i) ptrs[i] = args.in[i];
+    ptrs[kTriFields] = args.k;
+    ptrs[kTriFields + 1] = args.t_num;
+    ptrs[kTriFields + 2] = args.t_denom;
+    ptrs[kTriFields + 3] = args.hit;
+    const int v = pick_v(t.ops_per_lane, min_align(ptrs, kTriFields + 4), 4);
+    if (t.nontemporal) launch_tri_v<true>(args, n, v, stream);
+    else launch_tri_v<false>(args, n, v, stream);
+    return hipGetLastError();
+}
+
+template <bool EUC> static hipError_t launch_vec(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    uint32_t tile = t.vec_tile > 0 ? (uint32_t)t.vec_tile : 2048u;
+    tile = (tile + kSub - 1) / kSub * kSub;
+    const uint64_t blocks = (n + tile - 1) / tile;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (t.nontemporal) hipLaunchKernelGGL((k_vec<EUC, true>), dim3((unsigned)blocks), dim3(256), 0, stream, args, n, tile);
+    else hipLaunchKernelGGL((k_vec<EUC, false>), dim3((unsigned)blocks), dim3(256), 0, stream, args, n, tile);
+    return hipGetLastError();
+}
+
+hipError_t launch_euclid(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream) { return launch_vec<true>(args, n, t, stream); }
+hipError_t launch_angular(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream) { return launch_vec<false>(args, n, t, stream); }
+
+}  // namespace rtdp
