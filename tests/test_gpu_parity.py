@@ -1,0 +1,227 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+Integer / byte outputs (flags, hit words) and every FP output are compared as
+raw 32-bit patterns: no tolerance anywhere.
+"""
+import numpy as np
+import pytest
+
+from raytracer_amd import capi, gen
+
+from helpers import assert_bits_equal, hip_angular, hip_box, hip_euclid, hip_tri
+
+pytestmark = pytest.mark.gpu
+f32, u32 = np.float32, np.uint32
+
+
+def check_box(ctx, oracle, fields, device, torch=None):
+    tmin, flags = hip_box(ctx, fields, device, torch)
+    wt, wf = oracle.box_soa(fields)
+    for k in range(4):
+        assert_bits_equal(tmin[k], wt[k], "tmin_out[%d]" % k)
+    assert_bits_equal(flags, wf, "box flags")
+
+
+def check_tri(ctx, oracle, fields, k, device, torch=None):
+    tn, td, hit = hip_tri(ctx, fields, k, device, torch)
+    wn, wd, wh = oracle.tri_soa(fields, k)
+    assert_bits_equal(tn, wn, "t_num")
+    assert_bits_equal(td, wd, "t_denom")
+    assert_bits_equal(hit, wh, "triangle_hit")
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 255, 256, 257, 1023, 1025, 4099])
+@pytest.mark.parametrize("device", [False, True])
+def test_box_ragged_sizes(ctx, oracle, torch_cuda, n, device):
+    check_box(ctx, oracle, gen.box_ops(n, seed=100 + n, edge_frac=0.3), device, torch_cuda)
+
+
+@pytest.mark.parametrize("v", [1, 2, 4])
+@pytest.mark.parametrize("nt", [0, 1])
+def test_box_kernel_shapes(ctx, oracle, torch_cuda, v, nt):
+    ctx.set_tuning(ops_per_lane=v, nontemporal=nt)
+    check_box(ctx, oracle, gen.box_ops(200003, seed=7, edge_frac=0.25), True, torch_cuda)
+
+
+def test_box_random_1m(ctx, oracle, torch_cuda):
+    check_box(ctx, oracle, gen.box_ops(1 << 20, seed=20241008, edge_frac=0.0), True, torch_cuda)
+
+
+def test_box_edge_1m(ctx, oracle, torch_cuda):
+    check_box(ctx, oracle, gen.box_ops(1 << 20, seed=11, edge_frac=0.5), True, torch_cuda)
+
+
+def test_box_unaligned_views(ctx, oracle, torch_cuda):
+    """Arrays that start 4 or 8 bytes into an allocation take the narrower paths."""
+    torch = torch_cuda
+    n = 5000
+    fields = gen.box_ops(n, seed=5, edge_frac=0.2)
+    wt, wf = oracle.box_soa(fields)
+    for off in (1, 2, 3):
+        d = []
+        for f in fields:
+            buf = torch.zeros(n + 8, dtype=torch.float32, device="cuda")
+            buf[off:off + n] = torch.from_numpy(f).cuda()
+            d.append(buf[off:off + n])
+        tmin = [torch.empty(n + 8, dtype=torch.float32, device="cuda")[off:off + n] for _ in range(4)]
+        flags = torch.empty(n + 8, dtype=torch.int32, device="cuda")[off:off + n]
+        b = capi.Batch()
+        b.set_box(d, tmin, flags, n)
+        ctx.eval(b)
+        for k in range(4):
+            assert_bits_equal(tmin[k].cpu().numpy(), wt[k], "tmin_out[%d] off %d" % (k, off))
+        assert_bits_equal(flags.cpu().numpy(), wf, "flags off %d" % off)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 256, 1027, 4098])
+@pytest.mark.parametrize("device", [False, True])
+def test_tri_ragged_sizes(ctx, oracle, torch_cuda, n, device):
+    fields, k = gen.tri_ops(n, seed=200 + n, edge_frac=0.3)
+    check_tri(ctx, oracle, fields, k, device, torch_cuda)
+
+
+@pytest.mark.parametrize("v", [1, 2, 4])
+@pytest.mark.parametrize("nt", [0, 1])
+def test_tri_kernel_shapes(ctx, oracle, torch_cuda, v, nt):
+    ctx.set_tuning(ops_per_lane=v, nontemporal=nt)
+    fields, k = gen.tri_ops(200003, seed=8, edge_frac=0.25)
+    check_tri(ctx, oracle, fields, k, True, torch_cuda)
+
+
+def test_tri_random_and_edge_1m(ctx, oracle, torch_cuda):
+    fields, k = gen.tri_ops(1 << 20, seed=20241009, edge_frac=0.0)
+    check_tri(ctx, oracle, fields, k, True, torch_cuda)
+    fields, k = gen.tri_ops(1 << 20, seed=12, edge_frac=0.5)
+    check_tri(ctx, oracle, fields, k, True, torch_cuda)
+
+
+def check_euclid(ctx, oracle, a, b, ctl, device, torch, acc0=0.0):
+    ctx.set_accum([acc0, 0.0, 0.0])
+    out = hip_euclid(ctx, a, b, ctl, device, torch)
+    want, acc = oracle.euclid_beats(a, b, ctl, acc0)
+    assert_bits_equal(out, want, "euclidean_accumulator")
+    assert_bits_equal(ctx.get_accum()[0:1], np.array([acc], f32), "euclidean register after the batch")
+
+
+def check_angular(ctx, oracle, q, c, ctl, device, torch, d0=0.0, n0=0.0):
+    ctx.set_accum([0.0, d0, n0])
+    dot, norm = hip_angular(ctx, q, c, ctl, device, torch)
+    wd, wn, sd, sn = oracle.angular_beats(q, c, ctl, d0, n0)
+    assert_bits_equal(dot, wd, "angular_dot_product")
+    assert_bits_equal(norm, wn, "angular_norm")
+    assert_bits_equal(ctx.get_accum()[1:3], np.array([sd, sn], f32), "angular registers after the batch")
+
+
+@pytest.mark.parametrize("pairs", [1, 2, 17, 300, 5000])
+@pytest.mark.parametrize("device", [False, True])
+def test_euclid_pairs(ctx, oracle, torch_cuda, pairs, device):
+    a, b, ctl, _ = gen.vec_beats(pairs, 16, seed=300 + pairs, edge_frac=0.1)
+    check_euclid(ctx, oracle, a, b, ctl, device, torch_cuda)
+
+
+@pytest.mark.parametrize("pairs", [1, 2, 17, 300, 5000])
+@pytest.mark.parametrize("device", [False, True])
+def test_angular_pairs(ctx, oracle, torch_cuda, pairs, device):
+    q, c, ctl, _ = gen.vec_beats(pairs, 8, seed=400 + pairs, edge_frac=0.1)
+    check_angular(ctx, oracle, q, c, ctl, device, torch_cuda)
+
+
+@pytest.mark.parametrize("tile", [256, 512, 2048])
+def test_vec_tiles_and_long_pairs(ctx, oracle, torch_cuda, tile):
+    """Pairs longer than a sub-tile and longer than a whole tile; batch ends mid-pair;
+    batch starts with a carried-in register."""
+    ctx.set_tuning(vec_tile=tile)
+    lengths = np.array([16 * 700, 5, 16 * 300 + 3, 1, 16 * 2100, 40, 16 * 256, 16 * 257, 9], np.int64)
+    a, b, ctl, _ = gen.vec_beats(lengths.size, 16, seed=31, lengths=lengths)
+    ctl = ctl.copy()
+    ctl[-1] &= 0xFFFF  # the last pair continues into the next batch
+    check_euclid(ctx, oracle, a, b, ctl, True, torch_cuda, acc0=123.5)
+    lengths8 = (lengths // 2) + 1
+    q, c, ctl8, _ = gen.vec_beats(lengths8.size, 8, seed=32, lengths=lengths8)
+    ctl8 = ctl8.copy()
+    ctl8[-1] &= 0xFFFF
+    check_angular(ctx, oracle, q, c, ctl8, True, torch_cuda, d0=-3.25, n0=1e6)
+
+
+def test_vec_no_reset_anywhere(ctx, oracle, torch_cuda):
+    """One endless pair: every beat accumulates, no workgroup but the first has work."""
+    a, b, ctl, _ = gen.vec_beats(1, 16, seed=33, lengths=np.array([16 * 3000]))
+    ctl = (ctl & 0xFFFF).astype(u32)
+    check_euclid(ctx, oracle, a, b, ctl, True, torch_cuda, acc0=1.0)
+
+
+def test_accumulators_run_across_batches(ctx, oracle, torch_cuda):
+    """Splitting a stream into several calls gives the same results as one call."""
+    a, b, ctl, _ = gen.vec_beats(400, 16, seed=34)
+    want, acc = oracle.euclid_beats(a, b, ctl, 0.0)
+    ctx.reset()
+    cuts = [0, 1, 7, 300, 301, 900, ctl.shape[0]]
+    got = np.concatenate([hip_euclid(ctx, a[s:e], b[s:e], ctl[s:e], True, torch_cuda) for s, e in zip(cuts[:-1], cuts[1:])])
+    assert_bits_equal(got, want, "euclidean_accumulator over split batches")
+    assert_bits_equal(ctx.get_accum()[0:1], np.array([acc], f32), "register")
+
+
+def test_baseline_datapath_ignores_distance_ops(oracle, torch_cuda):
+    """RaytracerParams(support_euclidean = None): opcodes 2/3 produce zeros."""
+    c = capi.Context(support_euclidean=0)
+    a, b, ctl, _ = gen.vec_beats(50, 16, seed=35)
+    assert not hip_euclid(c, a, b, ctl, True, torch_cuda).any()
+    q, cc, ctl8, _ = gen.vec_beats(50, 8, seed=36)
+    d, n = hip_angular(c, q, cc, ctl8, False)
+    assert not d.any() and not n.any()
+    check_box(c, oracle, gen.box_ops(1000, seed=37), True, torch_cuda)
+    c.close()
+
+
+def test_mixed_bundle_stream_matches_rtl_oracle(ctx, oracle, torch_cuda):
+    """An unsorted stream of all four opcodes through rt_dp_eval_bundles against
+    oracle A (the gate-level restatement), including the accumulators interleaved
+    with other opcodes and the echoed reset bits."""
+    rng = np.random.default_rng(77)
+    wb = gen.aos_from_box(gen.box_ops(3000, seed=41, edge_frac=0.3))
+    wt = gen.aos_from_tri(*gen.tri_ops(3000, seed=42, edge_frac=0.3))
+    a, b, ctl, _ = gen.vec_beats(700, 16, seed=43, edge_frac=0.1)
+    we = gen.aos_from_vec(a, b, ctl, 2)
+    q, c, ctl8, _ = gen.vec_beats(400, 8, seed=44, edge_frac=0.1)
+    wa = gen.aos_from_vec(q, c, ctl8, 3)
+    # interleave while keeping each opcode's internal order (the accumulators need it)
+    tags = np.concatenate([np.full(w.shape[0], i) for i, w in enumerate((wb, wt, we, wa))])
+    rng.shuffle(tags)
+    srcs, pos = (wb, wt, we, wa), [0, 0, 0, 0]
+    stream = np.zeros((tags.size, 84), u32)
+    for i, t in enumerate(tags):
+        stream[i] = srcs[t][pos[t]]
+        pos[t] += 1
+    # box / triangle records of the extended test carry reset = 1, mask = 0 (Datapath_test.scala:399-409)
+    stream[stream[:, 0] < 2, 83] = 1
+    ctx.reset()
+    got = ctx.eval_bundles(stream)
+    want, state = oracle.eval_bundles("A", stream.view(oracle.IN_BUNDLE).reshape(-1), extended=True)
+    assert_bits_equal(got, want.view(u32).reshape(-1, 21), "output bundles")
+    acc = ctx.get_accum().view(u32)
+    assert tuple(int(x) for x in acc) == state
+
+
+def test_error_codes(ctx, torch_cuda):
+    b = capi.Batch()
+    b.ob.n[capi.OP_QUADBOX] = 10  # arrays missing
+    with pytest.raises(capi.RtDpError) as e:
+        ctx.eval(b)
+    assert e.value.code == capi.ENULL
+    b = capi.Batch()
+    b.ob.struct_size = 12
+    with pytest.raises(capi.RtDpError) as e:
+        ctx.eval(b)
+    assert e.value.code == capi.EINVAL
+    bad = np.zeros((3, 84), u32)
+    bad[1, 0] = 4
+    with pytest.raises(capi.RtDpError) as e:
+        ctx.eval_bundles(bad)
+    assert e.value.code == capi.EOPCODE
+    with pytest.raises(capi.RtDpError) as e:
+        capi.Context(support_euclidean=8)
+    assert e.value.code == capi.EINVAL and "16-element" in str(e.value)
+    with pytest.raises(capi.RtDpError) as e:
+        capi.Context(io_recorded_float=1)
+    assert "recorded-format" in str(e.value)
+    ctx.eval(capi.Batch())  # empty batch is fine
