@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Benchmark of the datapath evaluator on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A step is one pass of the hot path over one resident batch of synthetic
+operands.  Headline workload (N = 1): 2^24 random ray-vs-4-AABB box ops, SoA
+fp32 operands already in HBM.  With N > 1 every rank runs the same-size batch on
+its own GPU (independent op streams, no collective on the data path: weak
+scaling) and rank 0 prints the whole-job rate.
+
+One JSON line is printed by rank 0.  Besides the contract fields it carries
+  roofline      -- the dominant kernel against the HBM roof (algorithmic bytes)
+  cpu_baseline  -- the scalar C golden model (oracle B) timed on the host cores
+  per_opcode    -- the other three opcodes and a mixed batch, each with a roofline
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from raytracer_amd import capi, dist_util, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak
+# algorithmic bytes per unit of work: operands in + results out
+BYTES = {"box": 156, "tri": 76, "euclid": 136, "angular": 76}
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--log2-ops", type=int, default=24, help="ops per GPU of the headline box batch")
+    p.add_argument("--ops-per-lane", type=int, default=0)
+    p.add_argument("--nontemporal", type=int, default=0)
+    p.add_argument("--vec-tile", type=int, default=0)
+    p.add_argument("--only", default="", help="restrict to one workload: box|tri|euclid|angular|mixed")
+    # tuning: 0 = library default; nontemporal 1 = on, 2 = off
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=10.0)
+    p.add_argument("--sweep", action="store_true", help="A/B the kernel shapes instead of the timed run")
+    return p.parse_args()
+
+
+def make_batches(n, dev, which):
+    """Resident operand / result arrays and one capi.Batch per workload."""
+    out = {}
+    i32, f32 = torch.int32, torch.float32
+
+    def box(n_):
+        fields = synth.box_stream(n_, 20241008, dev)
+        tmin = [torch.empty(n_, dtype=f32, device=dev) for _ in range(4)]
+        flags = torch.empty(n_, dtype=i32, device=dev)
+        return fields, tmin, flags
+
+    def tri(n_):
+        fields, k = synth.tri_stream(n_, 20241009, dev)
+        return fields, k, torch.empty(n_, dtype=f32, device=dev), torch.empty(n_, dtype=f32, device=dev), torch.empty(n_, dtype=i32, device=dev)
+
+    def euc(n_):
+        a, b, ctl = synth.vec_stream(n_, 16, 20241010, dev)
+        return a, b, ctl, torch.empty(ctl.shape[0], dtype=f32, device=dev)
+
+    def ang(n_):
+        q, c, ctl = synth.vec_stream(n_, 8, 20241011, dev)
+        return q, c, ctl, torch.empty(ctl.shape[0], dtype=f32, device=dev), torch.empty(ctl.shape[0], dtype=f32, device=dev)
+
+    if "box" in which:
+        b = capi.Batch()
+        fields, tmin, flags = box(n)
+        b.set_box(fields, tmin, flags)
+        b.box_fields = fields
+        out["box"] = (b.finalize(), {"box": n})
+    if "tri" in which:
+        b = capi.Batch()
+        b.set_tri(*tri(n))
+        out["tri"] = (b.finalize(), {"tri": n})
+    if "euclid" in which:
+        b = capi.Batch()
+        e = euc(n)
+        b.set_euclid(*e)
+        out["euclid"] = (b.finalize(), {"euclid": int(e[2].shape[0])})
+    if "angular" in which:
+        b = capi.Batch()
+        a = ang(n)
+        b.set_angular(*a)
+        out["angular"] = (b.finalize(), {"angular": int(a[2].shape[0])})
+    if "mixed" in which:
+        # opcode ~ U{0..3}: a quarter of the stream per opcode, opcode-sorted segments
+        q = n // 4
+        b = capi.Batch()
+        b.set_box(*box(q))
+        b.set_tri(*tri(q))
+        e, a = euc(q), ang(q)
+        b.set_euclid(*e)
+        b.set_angular(*a)
+        out["mixed"] = (b.finalize(), {"box": q, "tri": q, "euclid": int(e[2].shape[0]), "angular": int(a[2].shape[0])})
+    return out
+
+
+_STREAM = None
+
+
+def bench_stream():
+    """A dedicated HIP stream: kernels are launched on it and the timing events are
+    recorded on it (a NULL handle would select the context's private stream)."""
+    global _STREAM
+    if _STREAM is None:
+        _STREAM = torch.cuda.Stream()
+    return _STREAM
+
+
+def sweep(ctx, batches, which, rounds=7, launches=10):
+    """Interleaved A/B of kernel shapes in one process: median / min device ms per launch."""
+    stream = bench_stream()
+    variants = {"box": [(v, nt, 0) for v in (1, 2, 4) for nt in (1, 2)],
+                "tri": [(v, nt, 0) for v in (1, 2, 4) for nt in (1, 2)],
+                "euclid": [(0, 1, t) for t in (256, 512, 768, 1024)],
+                "angular": [(0, 1, t) for t in (256, 512, 768, 1024)]}
+    rows = []
+    for name in which:
+        if name not in variants:
+            continue
+        batch, counts = batches[name]
+        algo = sum(BYTES[k] * v for k, v in counts.items())
+        times = {v: [] for v in variants[name]}
+        for _ in range(rounds):
+            for v in variants[name]:
+                ctx.set_tuning(*v)
+                ctx.launch(batch, stream.cuda_stream)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _i in range(launches):
+                    ctx.launch(batch, stream.cuda_stream)
+                e1.record(stream)
+                stream.synchronize()
+                times[v].append(e0.elapsed_time(e1) / launches)
+        for v, ts in times.items():
+            ts = sorted(ts)
+            med, mn = ts[len(ts) // 2], ts[0]
+            rows.append({"workload": name, "ops_per_lane": v[0], "nontemporal": v[1], "vec_tile": v[2],
+                         "median_ms": round(med, 4), "min_ms": round(mn, 4),
+                         "median_GBs": round(algo / med / 1e6, 1), "frac_of_8TBs": round(algo / med / 1e6 / HBM_PEAK_GBS, 4)})
+    return rows
+
+
+def run(ctx, batch, steps, warmup, dist):
+    """Returns (wall seconds for `steps` launches, max over ranks; device ms per launch on this rank)."""
+    stream = bench_stream()
+    for _ in range(warmup):
+        ctx.launch(batch, stream.cuda_stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for _ in range(steps):
+        ctx.launch(batch, stream.cuda_stream)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1) / steps
+    wall = dist_util.max_over_ranks(wall, device="cuda")
+    return wall, dev_ms
+
+
+def roofline(counts, dev_ms):
+    algo = sum(BYTES[k] * v for k, v in counts.items())
+    gbs = algo / (dev_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": load_traffic(counts)}
+
+
+def load_traffic(counts):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json:
+    {"box": bytes_per_op, ...}, already corrected as the gfx950 counter notes require), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        per_unit = json.load(open(path))
+        return int(sum(per_unit[k]["hbm_bytes_per_unit"] * v for k, v in counts.items()))
+    except Exception:
+        return None
+
+
+def cpu_baseline(batch, n, seconds):
+    """Oracle B (scalar C, one thread) on a bounded sample of the box batch."""
+    from oracle import dp_oracle as O  # the checker, used here only as the timed CPU port
+    O.build()
+    sample = min(n, 1 << 20)
+    host = [f[:sample].cpu().numpy() for f in batch.box_fields]  # first `sample` ops of each operand array
+    O.box_soa(host)  # warm
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        O.box_soa(host)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            break
+    return {"value": round(sample * reps / el, 1), "unit": "ops/s", "cores": 1, "kind": "port",
+            "sample": "first 2^%d box ops of the batch, %d passes, %.1f s, scalar C golden model (oracle B), 1 thread" % (
+                int(np.log2(sample)), reps, el)}
+
+
+def main():
+    a = parse()
+    world, rank, local = dist_util.env_world()
+    torch.cuda.set_device(local)
+    dist_util.init("nccl")  # RCCL; a no-op for a single process
+    dist = torch.distributed if world > 1 else None
+    dev = torch.device("cuda", local)
+    n = 1 << a.log2_ops
+
+    which = [a.only] if a.only else ["box", "tri", "euclid", "angular", "mixed"]
+    if world > 1 and not a.only:
+        which = ["box"]
+    ctx = capi.Context(device=local)
+    ctx.set_tuning(a.ops_per_lane, a.nontemporal, a.vec_tile)
+    batches = make_batches(n, dev, which)
+    torch.cuda.synchronize()
+
+    if a.sweep:
+        for row in sweep(ctx, batches, which):
+            print(json.dumps(row), flush=True)
+        ctx.close()
+        return
+
+    results = {}
+    for name in which:
+        batch, counts = batches[name]
+        wall, dev_ms = run(ctx, batch, a.steps, a.warmup, dist)
+        units = sum(counts.values())
+        results[name] = {"value": units * world * a.steps / wall, "ms_per_step": wall / a.steps * 1e3,
+                         "kernel_ms": dev_ms, "units_per_gpu": units, "roofline": roofline(counts, dev_ms)}
+
+    head = which[0]
+    r = results[head]
+    line = {
+        "metric": "datapath ops/s per opcode (whole node)" if head == "box" else "datapath ops/s (%s)" % head,
+        "value": round(r["value"], 1), "unit": "ops/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(r["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: 2^%d random ray-vs-4-AABB box ops per GPU, SoA fp32 operands resident in HBM" % (head, a.log2_ops)
+                   if head == "box" else "%s, 2^%d units per GPU" % (head, a.log2_ops),
+                   "ops_per_gpu": r["units_per_gpu"], "bytes_per_op": BYTES.get(head), "sharding": "independent op streams per GPU, no collective",
+                   "tuning": {"ops_per_lane": a.ops_per_lane, "nontemporal": a.nontemporal, "vec_tile": a.vec_tile}},
+        "roofline": r["roofline"],
+    }
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline and "box" in batches:
+            line["cpu_baseline"] = cpu_baseline(batches["box"][0], n, a.cpu_seconds)
+        else:
+            line["cpu_baseline"] = None
+        line["per_opcode"] = {k: {"value": round(v["value"], 1), "unit": "ops/s" if k in ("box", "tri", "mixed") else "beats/s",
+                                  "kernel_ms": round(v["kernel_ms"], 4), "units_per_gpu": v["units_per_gpu"], "roofline": v["roofline"]}
+                              for k, v in results.items()}
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    dist_util.shutdown()
+
+
+if __name__ == "__main__":
+    main()

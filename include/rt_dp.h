@@ -245,7 +245,8 @@ int rt_dp_eval_bundles(rt_dp_ctx *ctx, const rt_dp_input_bundle *in, rt_dp_outpu
  * Kernel-shape knobs (0 = library default), for A/B measurements; results do not
  * depend on them.  ops_per_lane: consecutive box / triangle ops one lane owns
  * (1, 2 or 4; lowered automatically when an array is not 8- / 16-byte aligned).
- * nontemporal: streaming loads and stores carry the `nt` cache hint.  vec_tile:
+ * nontemporal: streaming loads and stores carry the `nt` cache hint (1 on, 2 off).
+ * vec_tile:
  * nominal beats per workgroup for opcodes 2/3 (multiple of 256).  The same knobs
  * are read once per context from RT_DP_OPS_PER_LANE, RT_DP_NONTEMPORAL and
  * RT_DP_VEC_TILE.  No counterpart in the reference.                              */

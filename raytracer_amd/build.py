@@ -58,6 +58,12 @@ def build(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+    mb_src, mb = os.path.join(CSRC, "membench.hip"), os.path.join(LIBDIR, "membench")
+    if os.path.exists(mb_src) and (force or _stale(mb, [mb_src])):
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", mb_src, "-o", mb]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return LIB
 
 

@@ -387,7 +387,8 @@ int rt_dp_set_tuning(rt_dp_ctx *ctx, int ops_per_lane, int nontemporal, int vec_
     if (ops_per_lane != 0 && ops_per_lane != 1 && ops_per_lane != 2 && ops_per_lane != 4) return fail(RT_DP_EINVAL, "ops_per_lane must be 0, 1, 2 or 4");
     if (vec_tile < 0 || (vec_tile % 256) != 0) return fail(RT_DP_EINVAL, "vec_tile must be a non-negative multiple of 256");
     ctx->tuning.ops_per_lane = ops_per_lane;
-    ctx->tuning.nontemporal = nontemporal ? 1 : 0;
+    if (nontemporal < 0 || nontemporal > 2) return fail(RT_DP_EINVAL, "nontemporal must be 0 (default), 1 (on) or 2 (off)");
+    ctx->tuning.nontemporal = nontemporal;
     ctx->tuning.vec_tile = vec_tile;
     return RT_DP_OK;
 }

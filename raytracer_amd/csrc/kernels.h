@@ -37,7 +37,7 @@ struct VecArgs {
 // harness can A/B kernel shapes in one process.
 struct Tuning {
     int ops_per_lane;  // box / triangle: 1, 2 or 4 consecutive ops per lane
-    int nontemporal;   // 1: streaming loads/stores carry the nt cache hint
+    int nontemporal;   // streaming loads/stores carry the nt cache hint: 1 on, 2 off, 0 default
     int vec_tile;      // Euclidean / angular: nominal beats per workgroup (multiple of 256)
 };
 

@@ -416,6 +416,10 @@ template <bool NT> static void launch_tri_v(const TriArgs &a, uint64_t n, int v,
     else RTDP_LAUNCH_OPS(k_tri, a, n, 1, NT, s);
 }
 
+// Operand and result streams are touched exactly once, so by default they carry the
+// nt hint and do not displace each other in L2 / Infinity Cache.
+static bool use_nt(const Tuning &t) { return t.nontemporal != 2; }
+
 static int pick_v(int requested, int align_bytes, int dflt) {
     int v = requested > 0 ? requested : dflt;
     if (v != 1 && v != 2 && v != 4) v = dflt;
@@ -429,8 +433,8 @@ hipError_t launch_box(const BoxArgs &args, uint64_t n, const Tuning &t, hipStrea
     for (int i = 0; i < kBoxFields; ++i) ptrs[i] = args.in[i];
     for (int i = 0; i < 4; ++i) ptrs[kBoxFields + i] = args.tmin[i];
     ptrs[kBoxFields + 4] = args.flags;
-    const int v = pick_v(t.ops_per_lane, min_align(ptrs, kBoxFields + 5), 4);
-    if (t.nontemporal) launch_box_v<true>(args, n, v, stream);
+    const int v = pick_v(t.ops_per_lane, min_align(ptrs, kBoxFields + 5), 2);
+    if (use_nt(t)) launch_box_v<true>(args, n, v, stream);
     else launch_box_v<false>(args, n, v, stream);
     return hipGetLastError();
 }
@@ -443,19 +447,19 @@ hipError_t launch_tri(const TriArgs &args, uint64_t n, const Tuning &t, hipStrea
     ptrs[kTriFields + 1] = args.t_num;
     ptrs[kTriFields + 2] = args.t_denom;
     ptrs[kTriFields + 3] = args.hit;
-    const int v = pick_v(t.ops_per_lane, min_align(ptrs, kTriFields + 4), 4);
-    if (t.nontemporal) launch_tri_v<true>(args, n, v, stream);
+    const int v = pick_v(t.ops_per_lane, min_align(ptrs, kTriFields + 4), 2);
+    if (use_nt(t)) launch_tri_v<true>(args, n, v, stream);
     else launch_tri_v<false>(args, n, v, stream);
     return hipGetLastError();
 }
 
 template <bool EUC> static hipError_t launch_vec(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    uint32_t tile = t.vec_tile > 0 ? (uint32_t)t.vec_tile : 2048u;
+    uint32_t tile = t.vec_tile > 0 ? (uint32_t)t.vec_tile : 512u;
     tile = (tile + kSub - 1) / kSub * kSub;
     const uint64_t blocks = (n + tile - 1) / tile;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if (t.nontemporal) hipLaunchKernelGGL((k_vec<EUC, true>), dim3((unsigned)blocks), dim3(256), 0, stream, args, n, tile);
+    if (use_nt(t)) hipLaunchKernelGGL((k_vec<EUC, true>), dim3((unsigned)blocks), dim3(256), 0, stream, args, n, tile);
     else hipLaunchKernelGGL((k_vec<EUC, false>), dim3((unsigned)blocks), dim3(256), 0, stream, args, n, tile);
     return hipGetLastError();
 }

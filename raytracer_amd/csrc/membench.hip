@@ -1,0 +1,99 @@
+// HBM streaming calibration for gfx950: what a plain read / copy kernel reaches
+// on this box with the access widths the datapath kernels use.  Two uses:
+//   * the measured ceiling next to which the kernels' achieved GB/s is read;
+//   * known byte counts per kernel to calibrate rocprofv3's FETCH_SIZE /
+//     WRITE_SIZE for 4-, 8- and 16-byte-per-lane accesses.
+// Build: hipcc --offload-arch=gfx950 -O3 membench.hip -o membench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <typename T, bool NT, int STREAMS>
+__global__ __launch_bounds__(256) void k_read(const T *const in, T *sink, size_t n_per_stream) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_per_stream) return;
+    T acc = T(0);
+#pragma unroll
+    for (int s = 0; s < STREAMS; ++s) {
+        const T *p = in + (size_t)s * n_per_stream + i;
+        acc += NT ? __builtin_nontemporal_load(p) : *p;
+    }
+    // never true for the fill pattern: keeps the loads alive without writing
+    if (reinterpret_cast<float *>(&acc)[0] == 12345.678f) sink[i] = acc;
+}
+
+template <typename T, bool NT>
+__global__ __launch_bounds__(256) void k_copy(const T *in, T *out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (NT) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
+    else out[i] = in[i];
+}
+
+template <typename F> static double time_ms(F launch, int reps = 7) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    std::vector<float> ts;
+    launch();
+    CK(hipDeviceSynchronize());
+    for (int r = 0; r < reps; ++r) {
+        CK(hipEventRecord(e0));
+        launch();
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    return ts[ts.size() / 2];
+}
+
+template <typename T, bool NT, int STREAMS> static void run_read(const char *name, const void *buf, void *sink, size_t bytes) {
+    const size_t n = bytes / sizeof(T) / STREAMS;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    double ms = time_ms([&] { hipLaunchKernelGGL((k_read<T, NT, STREAMS>), dim3(blocks), dim3(256), 0, 0, (const T *)buf, (T *)sink, n); });
+    printf("%-28s %8.1f GB/s  (%.3f ms, %zu bytes read)\n", name, n * STREAMS * sizeof(T) / ms / 1e6, ms, n * STREAMS * sizeof(T));
+}
+
+template <typename T, bool NT> static void run_copy(const char *name, const void *in, void *out, size_t bytes) {
+    const size_t n = bytes / sizeof(T);
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    double ms = time_ms([&] { hipLaunchKernelGGL((k_copy<T, NT>), dim3(blocks), dim3(256), 0, 0, (const T *)in, (T *)out, n); });
+    printf("%-28s %8.1f GB/s  (%.3f ms, %zu bytes read + %zu written)\n", name, 2.0 * n * sizeof(T) / ms / 1e6, ms, n * sizeof(T), n * sizeof(T));
+}
+
+int main(int argc, char **argv) {
+    const size_t bytes = (argc > 1 ? (size_t)atoll(argv[1]) : 2048) << 20;  // MiB
+    void *a, *b;
+    CK(hipMalloc(&a, bytes));
+    CK(hipMalloc(&b, bytes));
+    CK(hipMemset(a, 0x11, bytes));
+    CK(hipMemset(b, 0x22, bytes));
+    CK(hipDeviceSynchronize());
+    run_read<float, false, 1>("read dword 1 stream", a, b, bytes);
+    run_read<float, true, 1>("read dword nt 1 stream", a, b, bytes);
+    run_read<f2v, false, 1>("read dwordx2 1 stream", a, b, bytes);
+    run_read<f2v, true, 1>("read dwordx2 nt 1 stream", a, b, bytes);
+    run_read<f4v, false, 1>("read dwordx4 1 stream", a, b, bytes);
+    run_read<f4v, true, 1>("read dwordx4 nt 1 stream", a, b, bytes);
+    run_read<float, true, 32>("read dword nt 32 streams", a, b, bytes);
+    run_read<f2v, true, 32>("read dwordx2 nt 32 streams", a, b, bytes);
+    run_read<f4v, true, 32>("read dwordx4 nt 32 streams", a, b, bytes);
+    run_read<f4v, false, 32>("read dwordx4 32 streams", a, b, bytes);
+    run_copy<float, false>("copy dword", a, b, bytes);
+    run_copy<f2v, true>("copy dwordx2 nt", a, b, bytes);
+    run_copy<f4v, false>("copy dwordx4", a, b, bytes);
+    run_copy<f4v, true>("copy dwordx4 nt", a, b, bytes);
+    CK(hipFree(a));
+    CK(hipFree(b));
+    return 0;
+}

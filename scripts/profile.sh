@@ -1,0 +1,27 @@
+#!/bin/bash
+# rocprofv3 passes behind the numbers in profiles/: one kernel-trace run of the
+# benchmark, then FETCH_SIZE / WRITE_SIZE counter passes (each in a run of its
+# own) for the benchmark and for the membench calibration kernels.
+# Usage (on the GPU box, from the repo root): bash scripts/profile.sh <tag>
+set -o pipefail
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+
+run() { # name, limit, command...
+    local name=$1 limit=$2; shift 2
+    echo "== $name" | tee -a "$OUT/log.txt"
+    timeout -s KILL "$limit" "$@" >> "$OUT/log.txt" 2>&1 || { echo "FAILED: $name" | tee -a "$OUT/log.txt"; exit 1; }
+}
+
+BENCH="python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+run kernel_trace 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $BENCH
+for wl in box tri euclid angular; do
+    run "fetch_$wl" 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_$wl" -- $BENCH --only $wl --steps 3 --warmup 1
+    run "write_$wl" 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_$wl" -- $BENCH --only $wl --steps 3 --warmup 1
+done
+run fetch_membench 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_membench" -- "$ROOT/raytracer_amd/lib/membench" 1024
+run write_membench 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_membench" -- "$ROOT/raytracer_amd/lib/membench" 1024
+echo "profile passes done" | tee -a "$OUT/log.txt"

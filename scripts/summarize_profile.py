@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 CSVs written by scripts/profile.sh into the small files
+kept under profiles/:
+
+  profiles/<tag>_kernel_trace.md   per kernel and grid size: calls, average duration
+  profiles/<tag>_pmc.md            FETCH_SIZE / WRITE_SIZE per dispatch, calibration, bytes per unit
+  profiles/traffic.json            HBM bytes per unit of work per opcode (read by bench.py)
+
+Counter handling for gfx950: FETCH_SIZE is reported in KiB and counts half of
+the bytes of a coalesced streaming read; the factor is re-measured here from the
+membench kernels, whose byte counts are known, for 4-, 8- and 16-byte-per-lane
+loads.  WRITE_SIZE (KiB) is calibrated the same way from the copy kernels.
+
+    python scripts/summarize_profile.py gpurun_out/prof_r01 r01
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+src, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles")
+os.makedirs(PROF, exist_ok=True)
+csv.field_size_limit(1 << 30)
+
+
+def short(name):
+    m = re.search(r"(rtdp::k_\w+<[^>]*>|k_read<[^>]*>|k_copy<[^>]*>)", name)
+    return m.group(1) if m else None
+
+
+def rows(pattern):
+    for path in glob.glob(os.path.join(src, pattern)):
+        with open(path, newline="") as f:
+            for r in csv.DictReader(f):
+                yield r
+
+
+# ---- kernel trace
+kt = defaultdict(list)
+for r in rows("kt/*/*kernel_trace.csv"):
+    k = short(r["Kernel_Name"])
+    if k:
+        grid = int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r.get("Grid_Size", 0))
+        kt[(k, grid)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+with open(os.path.join(PROF, tag + "_kernel_trace.md"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats, `python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline` (%s)\n\n" % tag)
+    f.write("Per kernel and grid size (threads); the first launch of each shape is excluded from the average.\n\n")
+    f.write("| kernel | grid (threads) | calls | avg us | min us | max us |\n|---|---|---|---|---|---|\n")
+    for (k, grid), d in sorted(kt.items()):
+        dd = d[1:] if len(d) > 1 else d
+        f.write("| `%s` | %d | %d | %.1f | %.1f | %.1f |\n" % (k, grid, len(d), sum(dd) / len(dd) / 1e3, min(dd) / 1e3, max(dd) / 1e3))
+
+# ---- counters
+def pmc(pattern, counter):
+    out = defaultdict(list)
+    for r in rows(pattern):
+        k = short(r["Kernel_Name"])
+        if k and r["Counter_Name"] == counter:
+            out[(k, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+    return out
+
+
+def med(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+lines = ["# FETCH_SIZE / WRITE_SIZE passes (%s)\n" % tag,
+         "Each counter was collected in a rocprofv3 run of its own (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`).\n",
+         "## Calibration on membench (1 GiB buffers, known byte counts)\n",
+         "| kernel | bytes moved | counter KiB (median) | bytes per counted KiB-unit |\n|---|---|---|---|"]
+GiB = 1 << 30
+fcal, wcal = {}, {}
+for (k, grid), v in sorted(pmc("pmc_fetch_membench/*/*counter_collection.csv", "FETCH_SIZE").items()):
+    if k.startswith("k_read"):
+        factor = GiB / (med(v) * 1024.0)
+        fcal[k] = factor
+        lines.append("| `%s` | %d read | %.1f | x%.3f |" % (k, GiB, med(v), factor))
+for (k, grid), v in sorted(pmc("pmc_write_membench/*/*counter_collection.csv", "WRITE_SIZE").items()):
+    if k.startswith("k_copy"):
+        factor = GiB / (med(v) * 1024.0)
+        wcal[k] = factor
+        lines.append("| `%s` | %d written | %.1f | x%.3f |" % (k, GiB, med(v), factor))
+ffac = sorted(fcal.values())[len(fcal) // 2] if fcal else 2.0
+wfac = sorted(wcal.values())[len(wcal) // 2] if wcal else 1.0
+lines.append("\nFETCH_SIZE correction used: x%.3f (KiB -> bytes: x1024, then the factor).  WRITE_SIZE correction: x%.3f.\n" % (ffac, wfac))
+
+UNITS = {"box": ("rtdp::k_box", 156, 136, 20), "tri": ("rtdp::k_tri", 76, 64, 12),
+         "euclid": ("rtdp::k_vec<true", 136, 132, 4), "angular": ("rtdp::k_vec<false", 76, 68, 8)}
+lines += ["## Datapath kernels (headline batch of each opcode)\n",
+          "| opcode | kernel | units per launch | fetched B/unit (algorithmic) | written B/unit (algorithmic) | HBM B/unit (algorithmic) |\n|---|---|---|---|---|---|"]
+traffic = {}
+units_log = {}
+for line in open(os.path.join(src, "log.txt")):
+    if line.startswith("{"):
+        try:
+            d = json.loads(line)
+        except Exception:
+            continue
+        for k, v in d.get("per_opcode", {}).items():
+            units_log[k] = v["units_per_gpu"]
+for op, (prefix, total, rd, wr) in UNITS.items():
+    fe = {k: v for k, v in pmc("pmc_fetch_%s/*/*counter_collection.csv" % op, "FETCH_SIZE").items() if k[0].startswith(prefix)}
+    we = {k: v for k, v in pmc("pmc_write_%s/*/*counter_collection.csv" % op, "WRITE_SIZE").items() if k[0].startswith(prefix)}
+    if not fe or not we or op not in units_log:
+        continue
+    key = max(fe, key=lambda k: k[1])  # the main launch (largest grid), not the tail launch
+    n = units_log[op]
+    fb = med(fe[key]) * 1024 * ffac / n
+    wb = med(we[key]) * 1024 * wfac / n
+    traffic[op] = {"hbm_bytes_per_unit": round(fb + wb, 2), "fetched": round(fb, 2), "written": round(wb, 2),
+                   "algorithmic": total, "units": n, "kernel": key[0]}
+    lines.append("| %s | `%s` | %d | %.2f (%d) | %.2f (%d) | %.2f (%d) |" % (op, key[0], n, fb, rd, wb, wr, fb + wb, total))
+open(os.path.join(PROF, tag + "_pmc.md"), "w").write("\n".join(lines) + "\n")
+json.dump(traffic, open(os.path.join(PROF, "traffic.json"), "w"), indent=1, sort_keys=True)
+print("\n".join(lines))

@@ -37,7 +37,7 @@ def test_box_ragged_sizes(ctx, oracle, torch_cuda, n, device):
 
 
 @pytest.mark.parametrize("v", [1, 2, 4])
-@pytest.mark.parametrize("nt", [0, 1])
+@pytest.mark.parametrize("nt", [1, 2])
 def test_box_kernel_shapes(ctx, oracle, torch_cuda, v, nt):
     ctx.set_tuning(ops_per_lane=v, nontemporal=nt)
     check_box(ctx, oracle, gen.box_ops(200003, seed=7, edge_frac=0.25), True, torch_cuda)
@@ -81,7 +81,7 @@ def test_tri_ragged_sizes(ctx, oracle, torch_cuda, n, device):
 
 
 @pytest.mark.parametrize("v", [1, 2, 4])
-@pytest.mark.parametrize("nt", [0, 1])
+@pytest.mark.parametrize("nt", [1, 2])
 def test_tri_kernel_shapes(ctx, oracle, torch_cuda, v, nt):
     ctx.set_tuning(ops_per_lane=v, nontemporal=nt)
     fields, k = gen.tri_ops(200003, seed=8, edge_frac=0.25)
