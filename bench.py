@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--ops-per-lane", type=int, default=0)
     p.add_argument("--nontemporal", type=int, default=0)
     p.add_argument("--vec-tile", type=int, default=0)
+    p.add_argument("--variant", type=int, default=0)
+    p.add_argument("--vec-passes", type=int, default=0)
     p.add_argument("--only", default="", help="restrict to one workload: box|tri|euclid|angular|mixed")
     # tuning: 0 = library default; nontemporal 1 = on, 2 = off
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -57,7 +59,8 @@ def make_batches(n, dev, which):
 
     def box(n_):
         fields = synth.box_stream(n_, 20241008, dev)
-        tmin = [torch.empty(n_, dtype=f32, device=dev) for _ in range(4)]
+        tm = torch.empty(4, n_, dtype=f32, device=dev)
+        tmin = [tm[0], tm[1], tm[2], tm[3]]
         flags = torch.empty(n_, dtype=i32, device=dev)
         return fields, tmin, flags
 
@@ -121,10 +124,15 @@ def bench_stream():
 def sweep(ctx, batches, which, rounds=7, launches=10):
     """Interleaved A/B of kernel shapes in one process: median / min device ms per launch."""
     stream = bench_stream()
-    variants = {"box": [(v, nt, 0) for v in (1, 2, 4) for nt in (1, 2)],
-                "tri": [(v, nt, 0) for v in (1, 2, 4) for nt in (1, 2)],
-                "euclid": [(0, 1, t) for t in (256, 512, 768, 1024)],
-                "angular": [(0, 1, t) for t in (256, 512, 768, 1024)]}
+    def V(ops_per_lane=0, nontemporal=1, vec_tile=0, variant=0, vec_passes=0):
+        return (ops_per_lane, nontemporal, vec_tile, variant, vec_passes)
+
+    ops = [V(v, nt) for v in (1, 2, 4) for nt in (1, 2)]
+    if os.environ.get("RT_DP_DIAG"):
+        ops = [V(2, 1), V(2, 1, 0, 10)]
+    variants = {"box": ops, "tri": ops,
+                "euclid": [V(vec_tile=t, vec_passes=p) for p in (2, 4, 8) for t in (64 * p, 128 * p)],
+                "angular": [V(vec_tile=t, vec_passes=p) for p in (2, 4, 8) for t in (128 * p, 256 * p)]}
     rows = []
     for name in which:
         if name not in variants:
@@ -146,7 +154,7 @@ def sweep(ctx, batches, which, rounds=7, launches=10):
         for v, ts in times.items():
             ts = sorted(ts)
             med, mn = ts[len(ts) // 2], ts[0]
-            rows.append({"workload": name, "ops_per_lane": v[0], "nontemporal": v[1], "vec_tile": v[2],
+            rows.append({"workload": name, "ops_per_lane": v[0], "nontemporal": v[1], "vec_tile": v[2], "variant": v[3], "vec_passes": v[4],
                          "median_ms": round(med, 4), "min_ms": round(mn, 4),
                          "median_GBs": round(algo / med / 1e6, 1), "frac_of_8TBs": round(algo / med / 1e6 / HBM_PEAK_GBS, 4)})
     return rows
@@ -229,7 +237,7 @@ def main():
     if world > 1 and not a.only:
         which = ["box"]
     ctx = capi.Context(device=local)
-    ctx.set_tuning(a.ops_per_lane, a.nontemporal, a.vec_tile)
+    ctx.set_tuning(a.ops_per_lane, a.nontemporal, a.vec_tile, a.variant, a.vec_passes)
     batches = make_batches(n, dev, which)
     torch.cuda.synchronize()
 
@@ -257,7 +265,7 @@ def main():
         "config": {"workload": "%s: 2^%d random ray-vs-4-AABB box ops per GPU, SoA fp32 operands resident in HBM" % (head, a.log2_ops)
                    if head == "box" else "%s, 2^%d units per GPU" % (head, a.log2_ops),
                    "ops_per_gpu": r["units_per_gpu"], "bytes_per_op": BYTES.get(head), "sharding": "independent op streams per GPU, no collective",
-                   "tuning": {"ops_per_lane": a.ops_per_lane, "nontemporal": a.nontemporal, "vec_tile": a.vec_tile}},
+                   "tuning": {"ops_per_lane": a.ops_per_lane, "nontemporal": a.nontemporal, "vec_tile": a.vec_tile, "variant": a.variant, "vec_passes": a.vec_passes}},
         "roofline": r["roofline"],
     }
     if rank == 0:

@@ -247,10 +247,15 @@ int rt_dp_eval_bundles(rt_dp_ctx *ctx, const rt_dp_input_bundle *in, rt_dp_outpu
  * (1, 2 or 4; lowered automatically when an array is not 8- / 16-byte aligned).
  * nontemporal: streaming loads and stores carry the `nt` cache hint (1 on, 2 off).
  * vec_tile:
- * nominal beats per workgroup for opcodes 2/3 (multiple of 256).  The same knobs
+ * nominal beats per workgroup for opcodes 2/3.  The same knobs
  * are read once per context from RT_DP_OPS_PER_LANE, RT_DP_NONTEMPORAL and
  * RT_DP_VEC_TILE.  No counterpart in the reference.                              */
 int rt_dp_set_tuning(rt_dp_ctx *ctx, int ops_per_lane, int nontemporal, int vec_tile);
+/* Further integer knobs by name: "vec_passes" (opcodes 2/3: 16-byte load pairs in flight per
+ * lane and sub-tile, 2 / 4 / 8), "variant" (0 normal; 10 diagnostic: the box kernel's memory
+ * pattern without its arithmetic, outputs meaningless).  Environment: RT_DP_VEC_PASSES,
+ * RT_DP_VARIANT. */
+int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value);
 
 const char *rt_dp_last_error(void);
 const char *rt_dp_version(void);

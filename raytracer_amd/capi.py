@@ -106,7 +106,7 @@ class OutputBundle(C.Structure):
 assert C.sizeof(InputBundle) == 84 * 4 and C.sizeof(OutputBundle) == 21 * 4
 
 EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize",
-           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning",
+           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option",
            "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
 
 
@@ -141,6 +141,7 @@ def load():
     L.rt_dp_set_accum.argtypes = [vp, C.POINTER(C.c_float * 3)]
     L.rt_dp_eval_bundles.argtypes = [vp, vp, vp, C.c_uint64]
     L.rt_dp_set_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.rt_dp_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.rt_dp_last_error.restype = C.c_char_p
     L.rt_dp_version.restype = C.c_char_p
     for name in EXPORTS:
@@ -292,8 +293,10 @@ class Context:
         a = (C.c_float * 3)(*[float(x) for x in acc])
         _check(self._L.rt_dp_set_accum(self._h, C.byref(a)))
 
-    def set_tuning(self, ops_per_lane=0, nontemporal=0, vec_tile=0):
+    def set_tuning(self, ops_per_lane=0, nontemporal=0, vec_tile=0, variant=0, vec_passes=0):
         _check(self._L.rt_dp_set_tuning(self._h, ops_per_lane, nontemporal, vec_tile))
+        _check(self._L.rt_dp_set_option(self._h, b"variant", variant))
+        _check(self._L.rt_dp_set_option(self._h, b"vec_passes", vec_passes))
 
     def eval_bundles(self, in_bundles):
         """in_bundles: numpy structured array whose itemsize equals sizeof(rt_dp_input_bundle)

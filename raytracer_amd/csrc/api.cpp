@@ -51,7 +51,7 @@ struct rt_dp_ctx {
     // grow-only staging for host-pointer batches
     char *d_stage = nullptr;
     size_t stage_bytes = 0;
-    Tuning tuning{0, 0, 0};
+    Tuning tuning{0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -296,6 +296,8 @@ int rt_dp_create(const rt_dp_config *cfg, rt_dp_ctx **out) {
     ctx->tuning.ops_per_lane = env_int("RT_DP_OPS_PER_LANE", 0);
     ctx->tuning.nontemporal = env_int("RT_DP_NONTEMPORAL", 0);
     ctx->tuning.vec_tile = env_int("RT_DP_VEC_TILE", 0);
+    ctx->tuning.variant = env_int("RT_DP_VARIANT", 0);
+    ctx->tuning.vec_passes = env_int("RT_DP_VEC_PASSES", 0);
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_state, 8 * sizeof(float));
     if (e == hipSuccess) e = hipMemsetAsync(ctx->d_state, 0, 8 * sizeof(float), ctx->stream);
@@ -385,11 +387,25 @@ int rt_dp_set_accum(rt_dp_ctx *ctx, const float acc[3]) {
 int rt_dp_set_tuning(rt_dp_ctx *ctx, int ops_per_lane, int nontemporal, int vec_tile) {
     if (!ctx) return fail(RT_DP_ENULL, "rt_dp_set_tuning: ctx is NULL");
     if (ops_per_lane != 0 && ops_per_lane != 1 && ops_per_lane != 2 && ops_per_lane != 4) return fail(RT_DP_EINVAL, "ops_per_lane must be 0, 1, 2 or 4");
-    if (vec_tile < 0 || (vec_tile % 256) != 0) return fail(RT_DP_EINVAL, "vec_tile must be a non-negative multiple of 256");
+    if (vec_tile < 0) return fail(RT_DP_EINVAL, "vec_tile must not be negative");
     ctx->tuning.ops_per_lane = ops_per_lane;
     if (nontemporal < 0 || nontemporal > 2) return fail(RT_DP_EINVAL, "nontemporal must be 0 (default), 1 (on) or 2 (off)");
     ctx->tuning.nontemporal = nontemporal;
     ctx->tuning.vec_tile = vec_tile;
+    return RT_DP_OK;
+}
+
+int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value) {
+    if (!ctx || !key) return fail(RT_DP_ENULL, "rt_dp_set_option: NULL argument");
+    if (!strcmp(key, "variant")) {
+        if (!(value == 0 || value == 10)) return fail(RT_DP_EINVAL, "variant must be 0 or 10 (diagnostic)");
+        ctx->tuning.variant = value;
+    } else if (!strcmp(key, "vec_passes")) {
+        if (value != 0 && value != 2 && value != 4 && value != 8) return fail(RT_DP_EINVAL, "vec_passes must be 0, 2, 4 or 8");
+        ctx->tuning.vec_passes = value;
+    } else {
+        return fail(RT_DP_EINVAL, "unknown option '%s'", key);
+    }
     return RT_DP_OK;
 }
 

@@ -38,7 +38,9 @@ struct VecArgs {
 struct Tuning {
     int ops_per_lane;  // box / triangle: 1, 2 or 4 consecutive ops per lane
     int nontemporal;   // streaming loads/stores carry the nt cache hint: 1 on, 2 off, 0 default
-    int vec_tile;      // Euclidean / angular: nominal beats per workgroup (multiple of 256)
+    int vec_tile;      // Euclidean / angular: nominal beats per workgroup
+    int variant;       // 0 normal; 10 diagnostic: the box kernel's memory pattern without its arithmetic
+    int vec_passes;    // Euclidean / angular: 16-byte load pairs in flight per lane and sub-tile (2, 4 or 8)
 };
 
 hipError_t launch_box(const BoxArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);

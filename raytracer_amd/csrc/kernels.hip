@@ -107,17 +107,15 @@ __device__ __forceinline__ void box_one(const float (&r)[kBoxFields], float (&t)
 }
 
 template <int V, bool NT>
-__global__ __launch_bounds__(256) void k_box(BoxArgs args, uint64_t first, uint64_t groups) {
+__device__ __forceinline__ void box_load(const BoxArgs &args, uint64_t i0, typename Pack<V>::F (&x)[kBoxFields]) {
+#pragma unroll
+    for (int f = 0; f < kBoxFields; ++f) x[f] = ld<typename Pack<V>::F, NT>(args.in[f] + i0);
+}
+
+template <int V, bool NT>
+__device__ __forceinline__ void box_eval_store(const BoxArgs &args, uint64_t i0, const typename Pack<V>::F (&x)[kBoxFields]) {
     using F = typename Pack<V>::F;
     using U = typename Pack<V>::U;
-    const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (g >= groups) return;
-    const uint64_t i0 = first + g * V;
-
-    F x[kBoxFields];
-#pragma unroll
-    for (int f = 0; f < kBoxFields; ++f) x[f] = ld<F, NT>(args.in[f] + i0);
-
     F to[4];
     U fo;
 #pragma unroll
@@ -134,6 +132,40 @@ __global__ __launch_bounds__(256) void k_box(BoxArgs args, uint64_t first, uint6
 #pragma unroll
     for (int k = 0; k < 4; ++k) st<F, NT>(args.tmin[k] + i0, to[k]);
     st<U, NT>(args.flags + i0, fo);
+}
+
+// One-shot shape: a lane owns V consecutive ops, issues all of its loads, then computes and stores.
+template <int V, bool NT>
+__global__ __launch_bounds__(256) void k_box(BoxArgs args, uint64_t first, uint64_t groups) {
+    const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (g >= groups) return;
+    const uint64_t i0 = first + g * V;
+    typename Pack<V>::F x[kBoxFields];
+    box_load<V, NT>(args, i0, x);
+    box_eval_store<V, NT>(args, i0, x);
+}
+
+// Diagnostic shape for bandwidth accounting (variant 10, never selected by default): the
+// box kernel's loads and stores with a trivial reduction in place of the datapath
+// arithmetic, i.e. what the memory pattern alone costs.  Its outputs are meaningless.
+template <int V>
+__global__ __launch_bounds__(256) void k_box_pattern(BoxArgs args, uint64_t groups) {
+    using F = typename Pack<V>::F;
+    using U = typename Pack<V>::U;
+    const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (g >= groups) return;
+    const uint64_t i0 = g * V;
+    F x[kBoxFields];
+    box_load<V, true>(args, i0, x);
+    F acc = x[0];
+#pragma unroll
+    for (int f = 1; f < kBoxFields; ++f) acc += x[f];
+    U fo;
+#pragma unroll
+    for (int v = 0; v < V; ++v) lane_setu<V>(fo, v, __float_as_uint(lane_get<V>(acc, v)));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st<F, true>(args.tmin[k] + i0, acc);
+    st<U, true>(args.flags + i0, fo);
 }
 
 // ----------------------------------------------------------------- Triangle
@@ -179,18 +211,16 @@ __device__ __forceinline__ void tri_one(const float (&r)[kTriFields], uint32_t k
 }
 
 template <int V, bool NT>
-__global__ __launch_bounds__(256) void k_tri(TriArgs args, uint64_t first, uint64_t groups) {
+__device__ __forceinline__ void tri_load(const TriArgs &args, uint64_t i0, typename Pack<V>::F (&x)[kTriFields], typename Pack<V>::U &kk) {
+#pragma unroll
+    for (int f = 0; f < kTriFields; ++f) x[f] = ld<typename Pack<V>::F, NT>(args.in[f] + i0);
+    kk = ld<typename Pack<V>::U, NT>(args.k + i0);
+}
+
+template <int V, bool NT>
+__device__ __forceinline__ void tri_eval_store(const TriArgs &args, uint64_t i0, const typename Pack<V>::F (&x)[kTriFields], const typename Pack<V>::U &kk) {
     using F = typename Pack<V>::F;
     using U = typename Pack<V>::U;
-    const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (g >= groups) return;
-    const uint64_t i0 = first + g * V;
-
-    F x[kTriFields];
-#pragma unroll
-    for (int f = 0; f < kTriFields; ++f) x[f] = ld<F, NT>(args.in[f] + i0);
-    const U kk = ld<U, NT>(args.k + i0);
-
     F on, od;
     U oh;
 #pragma unroll
@@ -209,6 +239,17 @@ __global__ __launch_bounds__(256) void k_tri(TriArgs args, uint64_t first, uint6
     st<U, NT>(args.hit + i0, oh);
 }
 
+template <int V, bool NT>
+__global__ __launch_bounds__(256) void k_tri(TriArgs args, uint64_t first, uint64_t groups) {
+    const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (g >= groups) return;
+    const uint64_t i0 = first + g * V;
+    typename Pack<V>::F x[kTriFields];
+    typename Pack<V>::U kk;
+    tri_load<V, NT>(args, i0, x, kk);
+    tri_eval_store<V, NT>(args, i0, x, kk);
+}
+
 // ------------------------------------------------- Euclidean / angular beats
 // A beat's 16 (8) element pairs are spread over 4 (2) adjacent lanes, four
 // elements per lane, so one wave-instruction loads 1 KiB of contiguous vector
@@ -222,12 +263,12 @@ __global__ __launch_bounds__(256) void k_tri(TriArgs args, uint64_t first, uint6
 // float sum over the beats of one vector pair, so it cannot be re-associated.
 // Each workgroup therefore owns whole vector pairs: its range starts at the
 // first pair boundary at or after blockIdx * tile and ends at the first pair
-// boundary at or after (blockIdx + 1) * tile.  Inside a 256-beat sub-tile the
+// boundary at or after (blockIdx + 1) * tile.  Inside a sub-tile (PASSES x 64 or x 128 beats) the
 // per-beat tree sums go to LDS and one lane per vector pair walks its beats in
 // order.  A pair longer than a tile is handled entirely by the workgroup in
 // whose nominal range it starts.
 
-constexpr int kSub = 256;  // beats per sub-tile == threads per workgroup
+constexpr int kThreads = 256;  // threads per workgroup of the beat kernels
 
 __device__ __forceinline__ float quad_xor1(float v) {  // quad_perm [1,0,3,2]
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
@@ -252,18 +293,18 @@ __device__ __forceinline__ uint64_t pair_boundary(const uint32_t *ctl, uint64_t 
     }
 }
 
-template <bool EUC, bool NT>
+template <bool EUC, bool NT, int PASSES>
 __global__ __launch_bounds__(256) void k_vec(VecArgs args, uint64_t n, uint32_t tile) {
     constexpr int LPB = EUC ? 4 : 2;         // lanes per beat
-    constexpr int BPP = kSub / LPB;          // beats per pass
-    constexpr int PASSES = LPB;              // passes per sub-tile
+    constexpr int BPP = kThreads / LPB;      // beats per pass
+    constexpr int SUB = PASSES * BPP;        // beats per sub-tile
     constexpr int ROW = EUC ? 16 : 8;        // floats per beat and vector
 
-    __shared__ float s_sum0[kSub];
-    __shared__ float s_sum1[EUC ? 1 : kSub];
-    __shared__ uint32_t s_ctl[kSub];
-    __shared__ float s_out0[kSub];
-    __shared__ float s_out1[EUC ? 1 : kSub];
+    __shared__ float s_sum0[SUB];
+    __shared__ float s_sum1[EUC ? 1 : SUB];
+    __shared__ uint32_t s_ctl[SUB];
+    __shared__ float s_out0[SUB];
+    __shared__ float s_out1[EUC ? 1 : SUB];
     __shared__ uint64_t s_range[2];
     __shared__ float s_carry[2][2];
 
@@ -283,8 +324,8 @@ __global__ __launch_bounds__(256) void k_vec(VecArgs args, uint64_t n, uint32_t 
 
     const int part = tid % LPB;  // which four elements of the beat
     int par = 0;
-    for (uint64_t base = lo; base < hi; base += kSub, par ^= 1) {
-        const int cnt = (hi - base < (uint64_t)kSub) ? (int)(hi - base) : kSub;
+    for (uint64_t base = lo; base < hi; base += SUB, par ^= 1) {
+        const int cnt = (hi - base < (uint64_t)SUB) ? (int)(hi - base) : SUB;
 
         // phase 1: tree sums of this sub-tile's beats
         f4v va[PASSES], vb[PASSES];
@@ -341,12 +382,12 @@ __global__ __launch_bounds__(256) void k_vec(VecArgs args, uint64_t n, uint32_t 
         __syncthreads();
 
         // phase 2: one lane per vector pair accumulates its beats in order
-        if (tid < cnt) {
-            const bool starts = (tid == 0) || (((s_ctl[tid - 1] >> 16) & 1u) != 0u);
+        for (int t0 = tid; t0 < cnt; t0 += kThreads) {
+            const bool starts = (t0 == 0) || (((s_ctl[t0 - 1] >> 16) & 1u) != 0u);
             if (starts) {
-                float acc0 = (tid == 0) ? s_carry[par][0] : 0.0f;
-                float acc1 = (tid == 0) ? s_carry[par][1] : 0.0f;
-                int i = tid;
+                float acc0 = (t0 == 0) ? s_carry[par][0] : 0.0f;
+                float acc1 = (t0 == 0) ? s_carry[par][1] : 0.0f;
+                int i = t0;
                 bool rs;
                 do {
                     const float o0 = acc0 + s_sum0[i];
@@ -369,9 +410,9 @@ __global__ __launch_bounds__(256) void k_vec(VecArgs args, uint64_t n, uint32_t 
         __syncthreads();
 
         // phase 3: coalesced result store
-        if (tid < cnt) {
-            st<float, NT>(args.out0 + base + tid, s_out0[tid]);
-            if (!EUC) st<float, NT>(args.out1 + base + tid, s_out1[tid]);
+        for (int t0 = tid; t0 < cnt; t0 += kThreads) {
+            st<float, NT>(args.out0 + base + t0, s_out0[t0]);
+            if (!EUC) st<float, NT>(args.out1 + base + t0, s_out1[t0]);
         }
     }
     if (hi == n && tid == 0) {  // the workgroup that owns the last beat hands the registers on
@@ -429,6 +470,11 @@ static int pick_v(int requested, int align_bytes, int dflt) {
 
 hipError_t launch_box(const BoxArgs &args, uint64_t n, const Tuning &t, hipStream_t stream) {
     if (n == 0) return hipSuccess;
+    if (t.variant == 10) {  // diagnostic: memory pattern only, 8-byte-aligned even-sized batches
+        const uint64_t groups = n / 2;
+        hipLaunchKernelGGL((k_box_pattern<2>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, args, groups);
+        return hipGetLastError();
+    }
     const void *ptrs[kBoxFields + 5];
     for (int i = 0; i < kBoxFields; ++i) ptrs[i] = args.in[i];
     for (int i = 0; i < 4; ++i) ptrs[kBoxFields + i] = args.tmin[i];
@@ -453,14 +499,24 @@ hipError_t launch_tri(const TriArgs &args, uint64_t n, const Tuning &t, hipStrea
     return hipGetLastError();
 }
 
+template <bool EUC, bool NT> static void launch_vec_p(const VecArgs &args, uint64_t n, uint32_t tile, int passes, unsigned blocks, hipStream_t stream) {
+    switch (passes) {
+    case 2: hipLaunchKernelGGL((k_vec<EUC, NT, 2>), dim3(blocks), dim3(kThreads), 0, stream, args, n, tile); break;
+    case 8: hipLaunchKernelGGL((k_vec<EUC, NT, 8>), dim3(blocks), dim3(kThreads), 0, stream, args, n, tile); break;
+    default: hipLaunchKernelGGL((k_vec<EUC, NT, 4>), dim3(blocks), dim3(kThreads), 0, stream, args, n, tile); break;
+    }
+}
+
 template <bool EUC> static hipError_t launch_vec(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream) {
     if (n == 0) return hipSuccess;
+    // defaults from an interleaved sweep on MI355X: sub-tile == tile == 512 beats for both opcodes
+    const int passes = (t.vec_passes == 2 || t.vec_passes == 4 || t.vec_passes == 8) ? t.vec_passes : (EUC ? 8 : 4);
     uint32_t tile = t.vec_tile > 0 ? (uint32_t)t.vec_tile : 512u;
-    tile = (tile + kSub - 1) / kSub * kSub;
+    if (tile < 64u) tile = 64u;
     const uint64_t blocks = (n + tile - 1) / tile;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if (use_nt(t)) hipLaunchKernelGGL((k_vec<EUC, true>), dim3((unsigned)blocks), dim3(256), 0, stream, args, n, tile);
-    else hipLaunchKernelGGL((k_vec<EUC, false>), dim3((unsigned)blocks), dim3(256), 0, stream, args, n, tile);
+    if (use_nt(t)) launch_vec_p<EUC, true>(args, n, tile, passes, (unsigned)blocks, stream);
+    else launch_vec_p<EUC, false>(args, n, tile, passes, (unsigned)blocks, stream);
     return hipGetLastError();
 }
 

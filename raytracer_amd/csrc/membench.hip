@@ -37,6 +37,55 @@ __global__ __launch_bounds__(256) void k_copy(const T *in, T *out, size_t n) {
     else out[i] = in[i];
 }
 
+template <typename T, bool NT, int STREAMS>
+__global__ __launch_bounds__(256) void k_write(T *out, size_t n_per_stream) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_per_stream) return;
+    T v = T((float)threadIdx.x);
+#pragma unroll
+    for (int s = 0; s < STREAMS; ++s) {
+        T *p = out + (size_t)s * n_per_stream + i;
+        if (NT) __builtin_nontemporal_store(v, p);
+        else *p = v;
+    }
+}
+
+// The box kernel's memory pattern without its arithmetic: RS read streams and WS write
+// streams of one element of type T per lane.  WIDE: lane pairs exchange their results so
+// that every store instruction writes 2 x sizeof(T) per lane on half of the arrays.
+template <typename T, int RS, int WS>
+__global__ __launch_bounds__(256) void k_mix(const T *in, T *out, size_t n_per_stream) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_per_stream) return;
+    T acc = T(0);
+#pragma unroll
+    for (int s = 0; s < RS; ++s) acc += __builtin_nontemporal_load(in + (size_t)s * n_per_stream + i);
+#pragma unroll
+    for (int s = 0; s < WS; ++s) __builtin_nontemporal_store(acc, out + (size_t)s * n_per_stream + i);
+}
+
+template <int RS, int WS>
+__global__ __launch_bounds__(256) void k_mix_wide(const f2v *in, f2v *out, size_t n_per_stream) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_per_stream) return;  // n_per_stream is a multiple of 256 in this benchmark
+    f2v acc = f2v(0);
+#pragma unroll
+    for (int s = 0; s < RS; ++s) acc += __builtin_nontemporal_load(in + (size_t)s * n_per_stream + i);
+    // partner's value through DPP quad_perm [1,0,3,2]
+    f2v oth;
+    oth.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc.x), 0xB1, 0xF, 0xF, true));
+    oth.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc.y), 0xB1, 0xF, 0xF, true));
+    const bool odd = threadIdx.x & 1;
+    f4v w;
+    w.x = odd ? oth.x : acc.x; w.y = odd ? oth.y : acc.y; w.z = odd ? acc.x : oth.x; w.w = odd ? acc.y : oth.y;
+    const size_t pair = i & ~(size_t)1;
+#pragma unroll
+    for (int s = 0; s < WS; s += 2) {
+        const int mine = s + (odd ? 1 : 0);
+        if (mine < WS) __builtin_nontemporal_store(w, reinterpret_cast<f4v *>(out + (size_t)mine * n_per_stream + pair));
+    }
+}
+
 template <typename F> static double time_ms(F launch, int reps = 7) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -71,6 +120,24 @@ template <typename T, bool NT> static void run_copy(const char *name, const void
     printf("%-28s %8.1f GB/s  (%.3f ms, %zu bytes read + %zu written)\n", name, 2.0 * n * sizeof(T) / ms / 1e6, ms, n * sizeof(T), n * sizeof(T));
 }
 
+template <typename T, bool NT, int STREAMS> static void run_write(const char *name, void *buf, size_t bytes) {
+    const size_t n = bytes / sizeof(T) / STREAMS;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    double ms = time_ms([&] { hipLaunchKernelGGL((k_write<T, NT, STREAMS>), dim3(blocks), dim3(256), 0, 0, (T *)buf, n); });
+    printf("%-28s %8.1f GB/s  (%.3f ms, %zu bytes written)\n", name, n * STREAMS * sizeof(T) / ms / 1e6, ms, n * STREAMS * sizeof(T));
+}
+
+template <typename T, int RS, int WS, bool WIDE> static void run_mix(const char *name, const void *in, void *out, size_t bytes) {
+    size_t n = bytes / sizeof(T) / RS;
+    n &= ~(size_t)255;
+    const unsigned blocks = (unsigned)(n / 256);
+    double ms;
+    if constexpr (WIDE) ms = time_ms([&] { hipLaunchKernelGGL((k_mix_wide<RS, WS>), dim3(blocks), dim3(256), 0, 0, (const f2v *)in, (f2v *)out, n); });
+    else ms = time_ms([&] { hipLaunchKernelGGL((k_mix<T, RS, WS>), dim3(blocks), dim3(256), 0, 0, (const T *)in, (T *)out, n); });
+    const double b = (double)n * sizeof(T) * (RS + WS);
+    printf("%-28s %8.1f GB/s  (%.3f ms, %d read + %d write streams)\n", name, b / ms / 1e6, ms, RS, WS);
+}
+
 int main(int argc, char **argv) {
     const size_t bytes = (argc > 1 ? (size_t)atoll(argv[1]) : 2048) << 20;  // MiB
     void *a, *b;
@@ -93,6 +160,19 @@ int main(int argc, char **argv) {
     run_copy<f2v, true>("copy dwordx2 nt", a, b, bytes);
     run_copy<f4v, false>("copy dwordx4", a, b, bytes);
     run_copy<f4v, true>("copy dwordx4 nt", a, b, bytes);
+    run_write<float, true, 1>("write dword nt", b, bytes);
+    run_write<f2v, true, 1>("write dwordx2 nt", b, bytes);
+    run_write<f4v, true, 1>("write dwordx4 nt", b, bytes);
+    run_write<f4v, false, 1>("write dwordx4", b, bytes);
+    run_write<f2v, true, 5>("write dwordx2 nt 5 streams", b, bytes);
+    run_write<f4v, true, 5>("write dwordx4 nt 5 streams", b, bytes);
+    run_mix<float, 34, 5, false>("mix 34r+5w dword", a, b, bytes);
+    run_mix<f2v, 34, 5, false>("mix 34r+5w dwordx2", a, b, bytes);
+    run_mix<f4v, 34, 5, false>("mix 34r+5w dwordx4", a, b, bytes);
+    run_mix<f2v, 34, 5, true>("mix 34r x2 + 5w x4 (paired)", a, b, bytes);
+    run_mix<f2v, 34, 0, false>("mix 34r+0w dwordx2", a, b, bytes);
+    run_mix<f2v, 16, 3, false>("mix 16r+3w dwordx2", a, b, bytes);
+    run_mix<f4v, 16, 3, false>("mix 16r+3w dwordx4", a, b, bytes);
     CK(hipFree(a));
     CK(hipFree(b));
     return 0;

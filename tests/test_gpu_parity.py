@@ -126,11 +126,11 @@ def test_angular_pairs(ctx, oracle, torch_cuda, pairs, device):
     check_angular(ctx, oracle, q, c, ctl, device, torch_cuda)
 
 
-@pytest.mark.parametrize("tile", [256, 512, 2048])
-def test_vec_tiles_and_long_pairs(ctx, oracle, torch_cuda, tile):
+@pytest.mark.parametrize("tile,passes", [(64, 2), (240, 4), (256, 2), (512, 0), (512, 8), (2048, 4)])
+def test_vec_tiles_and_long_pairs(ctx, oracle, torch_cuda, tile, passes):
     """Pairs longer than a sub-tile and longer than a whole tile; batch ends mid-pair;
     batch starts with a carried-in register."""
-    ctx.set_tuning(vec_tile=tile)
+    ctx.set_tuning(vec_tile=tile, vec_passes=passes)
     lengths = np.array([16 * 700, 5, 16 * 300 + 3, 1, 16 * 2100, 40, 16 * 256, 16 * 257, 9], np.int64)
     a, b, ctl, _ = gen.vec_beats(lengths.size, 16, seed=31, lengths=lengths)
     ctl = ctl.copy()
