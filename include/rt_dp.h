@@ -177,7 +177,9 @@ void rt_dp_destroy(rt_dp_ctx *ctx);
 
 /* Replaces driving UnifiedDatapath.in / .out for one batch (the chiseltest
  * enqueueSeq / waitForValid+peek loop of src/test/scala/raytracer_datapath/
- * Datapath_test.scala:275-302, :341-375, :476-496).  Synchronous: results are
+ * Datapath_test.scala:275-302, :341-375, :476-496).  Synchronous: with device
+ * pointers the call first waits for all work already queued on the device (the
+ * operands may still be in production on a caller stream), and results are
  * visible when it returns.  rt_dp_eval uses a per-thread default context on
  * the current device.                                                          */
 int rt_dp_eval(const rt_dp_op_batch *in, rt_dp_result_batch *out);
@@ -185,7 +187,9 @@ int rt_dp_eval_ctx(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch 
 
 /* Asynchronous form for callers that keep their streams in HBM: requires
  * RT_DP_F_DEVICE_PTRS, enqueues the kernels on `hip_stream` (a hipStream_t;
- * NULL = the context's own stream) and returns without synchronising.         */
+ * NULL = the context's own non-blocking stream) and returns without
+ * synchronising.  Ordering against the producers of the operands is the
+ * caller's: launch on the stream that produced them, or synchronise first.    */
 int rt_dp_launch(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *out, void *hip_stream);
 int rt_dp_synchronize(rt_dp_ctx *ctx);
 

@@ -346,6 +346,9 @@ int rt_dp_eval_ctx(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch 
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
     if (in->flags & RT_DP_F_DEVICE_PTRS) {
+        // The operands may still be in production on some other stream of the caller; the
+        // synchronous entry point waits for the whole device before it reads them.
+        HIP_TRY(hipDeviceSynchronize());
         rc = launch_device(ctx, in, out, ctx->stream);
         if (rc != RT_DP_OK) return rc;
         HIP_TRY(hipStreamSynchronize(ctx->stream));
