@@ -48,6 +48,8 @@ def parse():
     # tuning: 0 = library default; nontemporal 1 = on, 2 = off
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=10.0)
+    p.add_argument("--knn-log2-points", type=int, default=20)
+    p.add_argument("--knn-log2-queries", type=int, default=16)
     p.add_argument("--sweep", action="store_true", help="A/B the kernel shapes instead of the timed run")
     return p.parse_args()
 
@@ -224,6 +226,46 @@ def cpu_baseline(batch, n, seconds):
                 int(np.log2(sample)), reps, el)}
 
 
+def run_knn(a, world, rank, local, dev):
+    """k-NN configuration: 2^20 points (sharded over the ranks), 2^16 queries (replicated), dim 16, k = 16;
+    per-GPU partial lists merged after one all-gather.  Total work is fixed: strong scaling."""
+    from raytracer_amd import knn
+    n_pts, n_qry = 1 << a.knn_log2_points, 1 << a.knn_log2_queries
+    g = torch.Generator(device=dev)
+    g.manual_seed(20241012)
+    pts = torch.rand(n_pts, 16, generator=g, device=dev) * 2 - 1   # same on every rank
+    qry = torch.rand(n_qry, 16, generator=g, device=dev) * 2 - 1
+    lo, hi = (rank * n_pts) // world, ((rank + 1) * n_pts) // world
+    shard = pts[lo:hi].contiguous()
+    ctx = capi.Context(device=local)
+    stream = bench_stream()
+    times = []
+    with torch.cuda.stream(stream):
+        for it in range(a.warmup + a.steps):
+            torch.cuda.synchronize()
+            dist_util.barrier()
+            t0 = time.perf_counter()
+            d, i = knn.search(ctx, shard, qry, lo)
+            torch.cuda.synchronize()
+            dist_util.barrier()
+            if it >= a.warmup:
+                times.append(time.perf_counter() - t0)
+    wall = dist_util.max_over_ranks(sum(times), device="cuda")
+    if rank == 0:
+        per = wall / a.steps
+        pairs = float(n_pts) * n_qry
+        print(json.dumps({"metric": "k-NN queries/s (exact, Euclidean beat distance, k=16)", "value": round(n_qry / per, 1),
+                          "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": round(per * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "knn: 2^%d points sharded over %d GPU(s), 2^%d queries replicated, dim 16, k 16, one all-gather merge" % (
+                              a.knn_log2_points, world, a.knn_log2_queries)},
+                          "distance_beats_per_s": round(pairs / per, 1),
+                          "valu": {"lane_ops_per_pair": 47, "achieved_Tops": round(pairs * 47 / per / 1e12, 2), "peak_unfused_Tops": 39.3}}), flush=True)
+    ctx.close()
+    dist_util.shutdown()
+
+
 def main():
     a = parse()
     world, rank, local = dist_util.env_world()
@@ -232,6 +274,10 @@ def main():
     dist = torch.distributed if world > 1 else None
     dev = torch.device("cuda", local)
     n = 1 << a.log2_ops
+
+    if a.only == "knn":
+        run_knn(a, world, rank, local, dev)
+        return
 
     which = [a.only] if a.only else ["box", "tri", "euclid", "angular", "mixed"]
     if world > 1 and not a.only:

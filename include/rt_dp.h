@@ -245,6 +245,22 @@ typedef struct rt_dp_output_bundle {
 
 int rt_dp_eval_bundles(rt_dp_ctx *ctx, const rt_dp_input_bundle *in, rt_dp_output_bundle *out, uint64_t n);
 
+/* ---- k-nearest neighbours on the Euclidean distance op ------------------------------
+ * No counterpart in the reference's sources: the search layer that the distance
+ * opcodes exist for (hierarchical search, README.md:39-45 of the reference) is not part
+ * of its tree.  Exact top-16 per query over `n_points` 16-dimensional points, the
+ * distance being precisely the single-beat Euclidean op (mask 0xFFFF, reset 1;
+ * UnifiedDatapath.scala:221-245 ... :1133-1154).  All pointers are device pointers;
+ * points [n_points][16], queries [n_queries][16].  `splits` >= 1 cuts the points into
+ * that many ranges evaluated by separate workgroups; out_dist / out_idx are
+ * [splits][n_queries][16], each list ascending by (distance, index), where index =
+ * index_base + position of the point (so shards of a larger set report global indices).
+ * Unused slots hold (+Inf, 0xFFFFFFFF); a NaN distance never enters a list.  Partial lists
+ * (splits, GPUs) are combined by a (distance, index) merge, which makes the final result
+ * independent of the partition.  Asynchronous on `hip_stream` (NULL = context stream).   */
+int rt_dp_knn_euclid16(rt_dp_ctx *ctx, const float *points, uint32_t n_points, const float *queries, uint32_t n_queries,
+                       uint32_t index_base, uint32_t splits, float *out_dist, uint32_t *out_idx, void *hip_stream);
+
 /* ---- tuning and diagnostics ---------------------------------------------------
  * Kernel-shape knobs (0 = library default), for A/B measurements; results do not
  * depend on them.  ops_per_lane: consecutive box / triangle ops one lane owns

@@ -174,3 +174,25 @@ def angular_beats(q, c, ctl, dot=0.0, norm=0.0):
     sd, sn = np.array([dot], np.float32), np.array([norm], np.float32)
     lib().gold_angular_beats(ctl.size, _p(q), _p(c), _p(ctl), _p(d), _p(m), _p(sd), _p(sn))
     return d, m, sd[0], sn[0]
+
+
+def knn_bruteforce(points, queries, k=16, index_base=0):
+    """Exact k-NN by brute force with oracle B's Euclidean beat as the distance
+    (one beat per query/point pair, mask 0xFFFF, reset 1).  Ranked by (distance, index);
+    NaN distances are excluded.  Returns (dist [m, k] float32, idx [m, k] int64), padded
+    with (+Inf, 0xFFFFFFFF)."""
+    points = np.ascontiguousarray(points, np.float32)
+    queries = np.ascontiguousarray(queries, np.float32)
+    n, m = points.shape[0], queries.shape[0]
+    out_d = np.full((m, k), np.inf, np.float32)
+    out_i = np.full((m, k), 0xFFFFFFFF, np.int64)
+    ctl = np.full(n, 0x1FFFF, u32)
+    ids = np.arange(n, dtype=np.int64) + index_base
+    for q in range(m):
+        a = np.broadcast_to(queries[q], (n, 16)).copy()
+        d, _ = euclid_beats(a, points, ctl)
+        ok = ~np.isnan(d)
+        order = np.lexsort((ids[ok], d[ok]))[:k]
+        out_d[q, :order.size] = d[ok][order]
+        out_i[q, :order.size] = ids[ok][order]
+    return out_d, out_i

@@ -106,7 +106,7 @@ class OutputBundle(C.Structure):
 assert C.sizeof(InputBundle) == 84 * 4 and C.sizeof(OutputBundle) == 21 * 4
 
 EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize",
-           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option",
+           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16",
            "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
 
 
@@ -142,6 +142,7 @@ def load():
     L.rt_dp_eval_bundles.argtypes = [vp, vp, vp, C.c_uint64]
     L.rt_dp_set_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.rt_dp_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.rt_dp_knn_euclid16.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.rt_dp_last_error.restype = C.c_char_p
     L.rt_dp_version.restype = C.c_char_p
     for name in EXPORTS:
@@ -297,6 +298,17 @@ class Context:
         _check(self._L.rt_dp_set_tuning(self._h, ops_per_lane, nontemporal, vec_tile))
         _check(self._L.rt_dp_set_option(self._h, b"variant", variant))
         _check(self._L.rt_dp_set_option(self._h, b"vec_passes", vec_passes))
+
+    def knn_euclid16(self, points, queries, out_dist, out_idx, index_base=0, splits=1, stream=None):
+        """Top-16 nearest points per query (torch CUDA tensors): points [n,16], queries [m,16] float32,
+        out_dist [splits,m,16] float32, out_idx [splits,m,16] int32 (bit image of uint32).  Asynchronous."""
+        for t in (points, queries, out_dist, out_idx):
+            if not (t.is_cuda and t.is_contiguous()):
+                raise ValueError("knn_euclid16 needs contiguous CUDA tensors")
+        n, m = int(points.shape[0]), int(queries.shape[0])
+        assert tuple(out_dist.shape) == (splits, m, 16) and tuple(out_idx.shape) == (splits, m, 16)
+        _check(self._L.rt_dp_knn_euclid16(self._h, points.data_ptr(), n, queries.data_ptr(), m, index_base, splits,
+                                          out_dist.data_ptr(), out_idx.data_ptr(), C.c_void_p(stream) if stream else None))
 
     def eval_bundles(self, in_bundles):
         """in_bundles: numpy structured array whose itemsize equals sizeof(rt_dp_input_bundle)

@@ -398,6 +398,23 @@ int rt_dp_set_tuning(rt_dp_ctx *ctx, int ops_per_lane, int nontemporal, int vec_
     return RT_DP_OK;
 }
 
+int rt_dp_knn_euclid16(rt_dp_ctx *ctx, const float *points, uint32_t n_points, const float *queries, uint32_t n_queries,
+                       uint32_t index_base, uint32_t splits, float *out_dist, uint32_t *out_idx, void *hip_stream) {
+    if (!ctx) return fail(RT_DP_ENULL, "rt_dp_knn_euclid16: ctx is NULL");
+    if (n_queries == 0) return RT_DP_OK;
+    if (!queries || !out_dist || !out_idx || (n_points && !points)) return fail(RT_DP_ENULL, "rt_dp_knn_euclid16: NULL array");
+    if (splits == 0 || splits > 65535u) return fail(RT_DP_EINVAL, "splits must be 1..65535");
+    if ((uint64_t)index_base + n_points > 0xFFFFFFFFull) return fail(RT_DP_EINVAL, "index_base + n_points exceeds the 32-bit index range");
+    if ((reinterpret_cast<uintptr_t>(points) | reinterpret_cast<uintptr_t>(queries) | reinterpret_cast<uintptr_t>(out_dist) |
+         reinterpret_cast<uintptr_t>(out_idx)) & 3u)
+        return fail(RT_DP_EALIGN, "rt_dp_knn_euclid16: arrays must be 4-byte aligned");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
+    HIP_TRY(launch_knn_euclid16(points, n_points, queries, n_queries, index_base, splits, out_dist, out_idx,
+                                hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
+    return RT_DP_OK;
+}
+
 int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value) {
     if (!ctx || !key) return fail(RT_DP_ENULL, "rt_dp_set_option: NULL argument");
     if (!strcmp(key, "variant")) {

@@ -48,4 +48,9 @@ hipError_t launch_tri(const TriArgs &args, uint64_t n, const Tuning &t, hipStrea
 hipError_t launch_euclid(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
 hipError_t launch_angular(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
 
+// Exact top-16 nearest points per query under the datapath's Euclidean beat (dim 16).
+// out_d / out_i: [splits][n_qry][16], ascending by (distance, index); unused slots hold (+Inf, 0xFFFFFFFF).
+hipError_t launch_knn_euclid16(const float *pts, uint32_t n_pts, const float *qry, uint32_t n_qry, uint32_t idx_base,
+                               uint32_t splits, float *out_d, uint32_t *out_i, hipStream_t stream);
+
 }  // namespace rtdp

@@ -1,0 +1,115 @@
+"""k-NN on the Euclidean distance op: GPU kernel + merge against a brute-force oracle,
+and the all-gather merge rehearsed with two gloo ranks on CPU."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+f32 = np.float32
+
+
+def make_cloud(n, m, seed, specials=True):
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform(-1, 1, (n, 16)).astype(f32)
+    qry = rng.uniform(-1, 1, (m, 16)).astype(f32)
+    if specials and n >= 64:
+        pts[10] = pts[3]            # duplicate points: equal distances, lower index first
+        pts[11] = pts[3]
+        pts[20, 5] = np.nan         # NaN distance: never listed
+        pts[21, 0] = np.inf         # +Inf distance: listed last, before unused slots
+        pts[22] = qry[0]            # exact hit: distance +0
+        pts[23] *= f32(1e-30)       # squares underflow into the subnormal range
+        qry[1] = pts[40]
+    return pts, qry
+
+
+def test_merge_is_partition_independent():
+    import torch
+    from raytracer_amd import knn
+    rng = np.random.default_rng(0)
+    m = 50
+    d = torch.from_numpy(np.sort(rng.random((4, m, 16)).astype(f32), axis=2))
+    i = torch.from_numpy(rng.integers(0, 1 << 31, (4, m, 16)).astype(np.int32))
+    keys = knn.pack_keys(d, i)
+    whole = knn.merge_keys(keys)
+    halves = knn.merge_keys(torch.stack([knn.merge_keys(keys[:2]), knn.merge_keys(keys[2:])]))
+    assert torch.equal(whole, halves)
+    dd, ii = knn.unpack_keys(whole)
+    assert bool((dd[:, 1:] >= dd[:, :-1]).all())
+    # unsigned index order and the empty-slot key
+    assert knn.pack_keys(torch.tensor([1.0]), torch.tensor([-1], dtype=torch.int32)).item() > knn.pack_keys(torch.tensor([1.0]), torch.tensor([5], dtype=torch.int32)).item()
+    assert knn.pack_keys(torch.tensor([float("inf")]), torch.tensor([-1], dtype=torch.int32)).item() == knn.EMPTY_KEY
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,splits", [(1, 3, 1), (15, 5, 1), (2000, 300, 1), (2000, 300, 7), (5000, 257, None)])
+def test_knn_matches_bruteforce(ctx, oracle, torch_cuda, n, m, splits):
+    torch = torch_cuda
+    from raytracer_amd import knn
+    pts, qry = make_cloud(n, m, seed=n + m)
+    want_d, want_i = oracle.knn_bruteforce(pts, qry)
+    keys = knn.local_topk(ctx, torch.from_numpy(pts).cuda(), torch.from_numpy(qry).cuda(), 0, splits=splits)
+    d, i = knn.unpack_keys(keys)
+    assert (d.cpu().numpy().view(np.uint32) == want_d.view(np.uint32)).all()
+    assert (i.cpu().numpy() == want_i).all()
+
+
+@pytest.mark.gpu
+def test_knn_sharded_equals_unsharded(ctx, oracle, torch_cuda):
+    torch = torch_cuda
+    from raytracer_amd import knn
+    pts, qry = make_cloud(6000, 200, seed=5)
+    P, Q = torch.from_numpy(pts).cuda(), torch.from_numpy(qry).cuda()
+    whole = knn.local_topk(ctx, P, Q, 0)
+    cuts = [0, 1000, 1001, 4096, 6000]
+    parts = [knn.local_topk(ctx, P[s:e].contiguous(), Q, s) for s, e in zip(cuts[:-1], cuts[1:])]
+    assert torch.equal(knn.merge_keys(torch.stack(parts)), whole)
+    want_d, want_i = oracle.knn_bruteforce(pts, qry)
+    d, i = knn.unpack_keys(whole)
+    assert (i.cpu().numpy() == want_i).all() and (d.cpu().numpy().view(np.uint32) == want_d.view(np.uint32)).all()
+
+
+WORKER = r"""
+import sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+from raytracer_amd import dist_util, knn
+from oracle import dp_oracle as O
+world, rank, _ = dist_util.init("gloo")
+rng = np.random.default_rng(3)
+pts = rng.uniform(-1, 1, (3000, 16)).astype(np.float32)
+pts[100] = pts[2900]                      # a tie across the shard boundary
+qry = rng.uniform(-1, 1, (64, 16)).astype(np.float32)
+lo, hi = (rank * 3000) // world, ((rank + 1) * 3000) // world
+
+def local(p, q, base):                    # CPU stand-in for the GPU kernel: brute force with the oracle's beat
+    d, i = O.knn_bruteforce(p.numpy(), q.numpy(), 16, base)
+    return knn.pack_keys(torch.from_numpy(d), torch.from_numpy(i.astype(np.int64)).to(torch.int32))
+
+d, i = knn.search(None, torch.from_numpy(pts[lo:hi]), torch.from_numpy(qry), lo, local_fn=local)
+wd, wi = O.knn_bruteforce(pts, qry)
+assert (d.numpy().view(np.uint32) == wd.view(np.uint32)).all() and (i.numpy() == wi).all()
+every = dist_util.gather_objects(i.numpy().tobytes())
+assert all(e == every[0] for e in every)  # identical on every rank
+if rank == 0:
+    print("KNN-OK")
+dist_util.shutdown()
+"""
+
+
+def test_all_gather_merge_two_ranks_gloo(tmp_path, oracle):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    out = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "KNN-OK" in out.stdout
