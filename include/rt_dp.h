@@ -245,6 +245,24 @@ typedef struct rt_dp_output_bundle {
 
 int rt_dp_eval_bundles(rt_dp_ctx *ctx, const rt_dp_input_bundle *in, rt_dp_output_bundle *out, uint64_t n);
 
+/* ---- ray pre-processing (the step in front of the datapath) ---------------------------
+ * Derives, on the GPU, the ray fields that the reference's software model computes from
+ * (origin, dir) before it pokes a record: inv, kx/ky/kz and shear of SW_Ray
+ * (src/test/scala/raytracer_datapath/raytracer_gold/SW_Data.scala:36-82) and the constant
+ * extent 4000 (:55, :91-92).  Divisions are IEEE-754 correctly rounded like the JVM's;
+ * NaN results are written as 0x7FC00000.  Device pointers only; any output group may be
+ * NULL (inv: all three, shear: all three).  k is packed as in rt_dp_tri_in.
+ * Asynchronous on `hip_stream` (NULL = context stream).                                  */
+typedef struct rt_dp_ray_prep {
+    const float *dir[3];
+    float       *inv[3];
+    uint32_t    *k;
+    float       *shear[3];
+    float       *extent;
+} rt_dp_ray_prep;
+
+int rt_dp_ray_prepare(rt_dp_ctx *ctx, const rt_dp_ray_prep *rays, uint64_t n, void *hip_stream);
+
 /* ---- k-nearest neighbours on the Euclidean distance op ------------------------------
  * No counterpart in the reference's sources: the search layer that the distance
  * opcodes exist for (hierarchical search, README.md:39-45 of the reference) is not part

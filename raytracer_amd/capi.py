@@ -72,6 +72,10 @@ class Config(C.Structure):
                 ("internal_recorded_float", C.c_uint32), ("support_euclidean", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class RayPrep(C.Structure):
+    _fields_ = [("dir", _fp * 3), ("inv", _fp * 3), ("k", _fp), ("shear", _fp * 3), ("extent", _fp)]
+
+
 class F3(C.Structure):
     _fields_ = [("x", C.c_uint32), ("y", C.c_uint32), ("z", C.c_uint32)]
 
@@ -106,7 +110,7 @@ class OutputBundle(C.Structure):
 assert C.sizeof(InputBundle) == 84 * 4 and C.sizeof(OutputBundle) == 21 * 4
 
 EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize",
-           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16",
+           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_ray_prepare",
            "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
 
 
@@ -142,6 +146,7 @@ def load():
     L.rt_dp_eval_bundles.argtypes = [vp, vp, vp, C.c_uint64]
     L.rt_dp_set_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.rt_dp_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.rt_dp_ray_prepare.argtypes = [vp, C.POINTER(RayPrep), C.c_uint64, vp]
     L.rt_dp_knn_euclid16.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.rt_dp_last_error.restype = C.c_char_p
     L.rt_dp_version.restype = C.c_char_p
@@ -298,6 +303,22 @@ class Context:
         _check(self._L.rt_dp_set_tuning(self._h, ops_per_lane, nontemporal, vec_tile))
         _check(self._L.rt_dp_set_option(self._h, b"variant", variant))
         _check(self._L.rt_dp_set_option(self._h, b"vec_passes", vec_passes))
+
+    def ray_prepare(self, dirs, inv=None, k=None, shear=None, extent=None, stream=None):
+        """SW_Ray derivation on the GPU.  dirs / inv / shear: lists of three float32 CUDA tensors; k int32; extent float32."""
+        rp = RayPrep()
+        keep = set()
+        for c in range(3):
+            rp.dir[c] = _ptr(dirs[c], keep)
+            if inv is not None:
+                rp.inv[c] = _ptr(inv[c], keep)
+            if shear is not None:
+                rp.shear[c] = _ptr(shear[c], keep)
+        rp.k = _ptr(k, keep)
+        rp.extent = _ptr(extent, keep)
+        if keep != {"cuda"}:
+            raise ValueError("ray_prepare needs CUDA tensors")
+        _check(self._L.rt_dp_ray_prepare(self._h, C.byref(rp), int(dirs[0].shape[0]), C.c_void_p(stream) if stream else None))
 
     def knn_euclid16(self, points, queries, out_dist, out_idx, index_base=0, splits=1, stream=None):
         """Top-16 nearest points per query (torch CUDA tensors): points [n,16], queries [m,16] float32,

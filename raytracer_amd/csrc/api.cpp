@@ -398,6 +398,27 @@ int rt_dp_set_tuning(rt_dp_ctx *ctx, int ops_per_lane, int nontemporal, int vec_
     return RT_DP_OK;
 }
 
+int rt_dp_ray_prepare(rt_dp_ctx *ctx, const rt_dp_ray_prep *rays, uint64_t n, void *hip_stream) {
+    if (!ctx || !rays) return fail(RT_DP_ENULL, "rt_dp_ray_prepare: NULL argument");
+    if (n == 0) return RT_DP_OK;
+    if (n > kMaxOps) return fail(RT_DP_EINVAL, "n = %llu is not representable (limit 2^40)", (unsigned long long)n);
+    RayPrepArgs a;
+    for (int c = 0; c < 3; ++c) {
+        if (!rays->dir[c]) return fail(RT_DP_ENULL, "rt_dp_ray_prepare: dir[] is NULL");
+        a.dir[c] = rays->dir[c];
+        a.inv[c] = rays->inv[c];
+        a.shear[c] = rays->shear[c];
+    }
+    if ((!a.inv[0]) != (!a.inv[1]) || (!a.inv[0]) != (!a.inv[2])) return fail(RT_DP_ENULL, "rt_dp_ray_prepare: give all three inv arrays or none");
+    if ((!a.shear[0]) != (!a.shear[1]) || (!a.shear[0]) != (!a.shear[2])) return fail(RT_DP_ENULL, "rt_dp_ray_prepare: give all three shear arrays or none");
+    a.k = rays->k;
+    a.extent = rays->extent;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
+    HIP_TRY(launch_ray_prepare(a, n, hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
+    return RT_DP_OK;
+}
+
 int rt_dp_knn_euclid16(rt_dp_ctx *ctx, const float *points, uint32_t n_points, const float *queries, uint32_t n_queries,
                        uint32_t index_base, uint32_t splits, float *out_dist, uint32_t *out_idx, void *hip_stream) {
     if (!ctx) return fail(RT_DP_ENULL, "rt_dp_knn_euclid16: ctx is NULL");

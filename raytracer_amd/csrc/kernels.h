@@ -33,6 +33,14 @@ struct VecArgs {
     float *state_out;       // accumulator register(s) after the last beat
 };
 
+struct RayPrepArgs {
+    const float *dir[3];
+    float *inv[3];     // all three NULL: not wanted
+    uint32_t *k;       // NULL: not wanted
+    float *shear[3];   // all three NULL: not wanted
+    float *extent;     // NULL: not wanted
+};
+
 // Tunables, settable per launch (0 = library default).  Exposed so the bench
 // harness can A/B kernel shapes in one process.
 struct Tuning {
@@ -47,6 +55,8 @@ hipError_t launch_box(const BoxArgs &args, uint64_t n, const Tuning &t, hipStrea
 hipError_t launch_tri(const TriArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
 hipError_t launch_euclid(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
 hipError_t launch_angular(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
+
+hipError_t launch_ray_prepare(const RayPrepArgs &args, uint64_t n, hipStream_t stream);
 
 // Exact top-16 nearest points per query under the datapath's Euclidean beat (dim 16).
 // out_d / out_i: [splits][n_qry][16], ascending by (distance, index); unused slots hold (+Inf, 0xFFFFFFFF).

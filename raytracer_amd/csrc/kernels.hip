@@ -421,6 +421,51 @@ __global__ __launch_bounds__(256) void k_vec(VecArgs args, uint64_t n, uint32_t 
     }
 }
 
+// ------------------------------------------------------- ray pre-processing
+// The step in front of the datapath: the ray fields that the reference's software model
+// derives from (origin, dir) before a record is poked into the RTL (reference
+// src/test/scala/raytracer_datapath/raytracer_gold/SW_Data.scala:36-82):
+//   inv = 1.0f / dir                         (IEEE-754 correctly rounded division)
+//   kz  = index of the largest |dir| component, ties keep the lower axis (strict >, :36-53)
+//   kx  = (kz + 1) % 3, ky = (kx + 1) % 3, exchanged when dir[kz] < 0     (:64-76)
+//   shear = (dir[kx] / dir[kz], dir[ky] / dir[kz], 1.0f / dir[kz])         (:78-82)
+//   extent = 4000.0f                                                        (:55, :91-92)
+// NaN results are written as 0x7FC00000; every consumer in the datapath is blind to
+// NaN sign and payload.
+__global__ __launch_bounds__(256) void k_ray_prepare(RayPrepArgs a, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float d[3] = {a.dir[0][i], a.dir[1][i], a.dir[2][i]};
+    if (a.inv[0]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.inv[c][i] = canon_nan(1.0f / d[c]);
+    }
+    const float ax = fabsf(d[0]), ay = fabsf(d[1]), az = fabsf(d[2]);
+    uint32_t kz = 0u;
+    float m = ax;
+    if (ay > m) { m = ay; kz = 1u; }
+    if (az > m) { kz = 2u; }
+    uint32_t kx = (kz + 1u == 3u) ? 0u : kz + 1u;
+    uint32_t ky = (kx + 1u == 3u) ? 0u : kx + 1u;
+    const float dz = at3(d[0], d[1], d[2], kz);
+    if (dz < 0.0f) { const uint32_t t = kx; kx = ky; ky = t; }
+    if (a.k) a.k[i] = kx | (ky << 2) | (kz << 4);
+    if (a.shear[0]) {
+        a.shear[0][i] = canon_nan(at3(d[0], d[1], d[2], kx) / dz);
+        a.shear[1][i] = canon_nan(at3(d[0], d[1], d[2], ky) / dz);
+        a.shear[2][i] = canon_nan(1.0f / dz);
+    }
+    if (a.extent) a.extent[i] = 4000.0f;
+}
+
+hipError_t launch_ray_prepare(const RayPrepArgs &args, uint64_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_ray_prepare, dim3((unsigned)blocks), dim3(256), 0, stream, args, n);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- launchers
 
 static inline int min_align(const void *const *ptrs, int count) {

@@ -225,3 +225,39 @@ def test_error_codes(ctx, torch_cuda):
         capi.Context(io_recorded_float=1)
     assert "recorded-format" in str(e.value)
     ctx.eval(capi.Batch())  # empty batch is fine
+
+
+def test_ray_prepare_follows_sw_ray(ctx, torch_cuda):
+    """The pre-processing kernel against the float32 restatement of SW_Ray (gen.ray_derived),
+    including zero, subnormal, huge and non-finite direction components and |dir| ties."""
+    torch = torch_cuda
+    rng = np.random.default_rng(50)
+    n = 200000
+    d = rng.uniform(-100, 100, (n, 3)).astype(f32)
+    sp = np.array([0.0, -0.0, 1e-42, -1e-42, 3e38, -3e38, np.inf, -np.inf, 1.0, -1.0, 2.0 ** -126, 1e-20], f32)
+    rows = rng.choice(n, n // 10, replace=False)
+    d[rows, rng.integers(0, 3, rows.size)] = sp[rng.integers(0, sp.size, rows.size)]
+    ties = rng.choice(n, 2000, replace=False)
+    d[ties, 1] = d[ties, 0] * rng.choice(np.array([1, -1], f32), ties.size)   # |x| == |y|
+    d[ties[:500], 2] = d[ties[:500], 0]
+    inv, kx, ky, kz, shear = gen.ray_derived(d)
+    D = [torch.from_numpy(np.ascontiguousarray(d[:, c])).cuda() for c in range(3)]
+    oi = [torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(3)]
+    os_ = [torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(3)]
+    ok = torch.empty(n, dtype=torch.int32, device="cuda")
+    oe = torch.empty(n, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.ray_prepare(D, inv=oi, k=ok, shear=os_, extent=oe)
+    ctx.synchronize()
+
+    def canon(x):
+        b = np.ascontiguousarray(x, f32).view(u32).copy()
+        b[np.isnan(x)] = 0x7FC00000
+        return b
+    for c in range(3):
+        assert (oi[c].cpu().numpy().view(u32) == canon(inv[:, c])).all(), "inv[%d]" % c
+    finite = np.isfinite(d).all(1)   # SW_Ray's comparisons with a NaN direction are not exercised by the reference
+    assert (ok.cpu().numpy().view(u32)[finite] == gen.pack_k(kx, ky, kz)[finite]).all()
+    for c in range(3):
+        assert (os_[c].cpu().numpy().view(u32)[finite] == canon(shear[:, c])[finite]).all(), "shear[%d]" % c
+    assert (oe.cpu().numpy() == 4000.0).all()
