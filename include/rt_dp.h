@@ -245,6 +245,12 @@ typedef struct rt_dp_output_bundle {
 
 int rt_dp_eval_bundles(rt_dp_ctx *ctx, const rt_dp_input_bundle *in, rt_dp_output_bundle *out, uint64_t n);
 
+/* The same contract for a record stream that already lives in HBM (device pointers,
+ * n < 2^29): the opcode partition (stable, so every accumulator sees its beats in
+ * stream order), the evaluation and the re-assembly of the output records all run on
+ * the GPU; only the four per-opcode counts travel to the host.  Synchronous.           */
+int rt_dp_eval_bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt_dp_output_bundle *d_out, uint64_t n);
+
 /* ---- ray pre-processing (the step in front of the datapath) ---------------------------
  * Derives, on the GPU, the ray fields that the reference's software model computes from
  * (origin, dir) before it pokes a record: inv, kx/ky/kz and shear of SW_Ray

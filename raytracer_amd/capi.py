@@ -110,7 +110,7 @@ class OutputBundle(C.Structure):
 assert C.sizeof(InputBundle) == 84 * 4 and C.sizeof(OutputBundle) == 21 * 4
 
 EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize",
-           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_ray_prepare",
+           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
            "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
 
 
@@ -144,6 +144,7 @@ def load():
     L.rt_dp_get_accum.argtypes = [vp, C.POINTER(C.c_float * 3)]
     L.rt_dp_set_accum.argtypes = [vp, C.POINTER(C.c_float * 3)]
     L.rt_dp_eval_bundles.argtypes = [vp, vp, vp, C.c_uint64]
+    L.rt_dp_eval_bundles_device.argtypes = [vp, vp, vp, C.c_uint64]
     L.rt_dp_set_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.rt_dp_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.rt_dp_ray_prepare.argtypes = [vp, C.POINTER(RayPrep), C.c_uint64, vp]
@@ -303,6 +304,12 @@ class Context:
         _check(self._L.rt_dp_set_tuning(self._h, ops_per_lane, nontemporal, vec_tile))
         _check(self._L.rt_dp_set_option(self._h, b"variant", variant))
         _check(self._L.rt_dp_set_option(self._h, b"vec_passes", vec_passes))
+
+    def eval_bundles_device(self, d_in, d_out):
+        """Record stream resident in HBM: d_in int32 CUDA tensor [n, 84], d_out int32 CUDA tensor [n, 21]."""
+        assert d_in.is_cuda and d_out.is_cuda and d_in.is_contiguous() and d_out.is_contiguous()
+        assert d_in.shape[1] == 84 and tuple(d_out.shape) == (d_in.shape[0], 21)
+        _check(self._L.rt_dp_eval_bundles_device(self._h, d_in.data_ptr(), d_out.data_ptr(), int(d_in.shape[0])))
 
     def ray_prepare(self, dirs, inv=None, k=None, shear=None, extent=None, stream=None):
         """SW_Ray derivation on the GPU.  dirs / inv / shear: lists of three float32 CUDA tensors; k int32; extent float32."""

@@ -51,6 +51,9 @@ struct rt_dp_ctx {
     // grow-only staging for host-pointer batches
     char *d_stage = nullptr;
     size_t stage_bytes = 0;
+    // grow-only workspace of the device-side record stream path (slots, block offsets)
+    char *d_stream = nullptr;
+    size_t stream_bytes = 0;
     Tuning tuning{0, 0, 0, 0, 0};
 };
 
@@ -316,6 +319,7 @@ void rt_dp_destroy(rt_dp_ctx *ctx) {
     DeviceGuard guard(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->d_stream) (void)hipFree(ctx->d_stream);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (g_default_ctx == ctx) g_default_ctx = nullptr;
@@ -395,6 +399,95 @@ int rt_dp_set_tuning(rt_dp_ctx *ctx, int ops_per_lane, int nontemporal, int vec_
     if (nontemporal < 0 || nontemporal > 2) return fail(RT_DP_EINVAL, "nontemporal must be 0 (default), 1 (on) or 2 (off)");
     ctx->tuning.nontemporal = nontemporal;
     ctx->tuning.vec_tile = vec_tile;
+    return RT_DP_OK;
+}
+
+// Record stream resident in HBM: partition, evaluate and re-assemble on the device.
+int rt_dp_eval_bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt_dp_output_bundle *d_out, uint64_t n) {
+    if (!ctx) return fail(RT_DP_ENULL, "rt_dp_eval_bundles_device: ctx is NULL");
+    if (n == 0) return RT_DP_OK;
+    if (!d_in || !d_out) return fail(RT_DP_ENULL, "rt_dp_eval_bundles_device: in/out is NULL");
+    if (n >= (1ull << 29)) return fail(RT_DP_EINVAL, "rt_dp_eval_bundles_device: at most 2^29 - 1 records per call");
+    if ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 3u) return fail(RT_DP_EALIGN, "record arrays must be 4-byte aligned");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipDeviceSynchronize());  // the records may still be in production on a caller stream
+
+    auto grow = [&](char *&buf, size_t &have, size_t want) -> int {
+        if (want <= have) return RT_DP_OK;
+        if (buf) { (void)hipFree(buf); buf = nullptr; have = 0; }
+        want += want / 4;
+        hipError_t e = hipMalloc(&buf, want);
+        if (e != hipSuccess) return fail(RT_DP_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        have = want;
+        return RT_DP_OK;
+    };
+    const uint64_t nblk = (n + 255) / 256;
+    const size_t off_slot = 0, off_cnt = align_up(n * 4), off_tot = off_cnt + align_up(nblk * 16);
+    int rc = grow(ctx->d_stream, ctx->stream_bytes, off_tot + 256);
+    if (rc != RT_DP_OK) return rc;
+    uint32_t *slot = reinterpret_cast<uint32_t *>(ctx->d_stream + off_slot);
+    uint32_t *blockcnt = reinterpret_cast<uint32_t *>(ctx->d_stream + off_cnt);
+    uint32_t *totals = reinterpret_cast<uint32_t *>(ctx->d_stream + off_tot);
+    const uint32_t *in_words = reinterpret_cast<const uint32_t *>(d_in);
+
+    HIP_TRY(stream_count_scan(in_words, n, blockcnt, totals, s));
+    uint32_t h[8];
+    HIP_TRY(hipMemcpyAsync(h, totals, sizeof h, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (h[4]) return fail(RT_DP_EOPCODE, "the record stream holds an opcode > 3; the RTL's opcode field is 2 bits wide");
+    const uint64_t nt = h[0], nb = h[1], ne = h[2], na = h[3];
+
+    // carve the structure-of-arrays segments (operands and results) out of the staging buffer
+    size_t total = 0;
+    auto take = [&](size_t bytes) { size_t o = total; total += align_up(bytes ? bytes : 4); return o; };
+    size_t o_box[kBoxFields], o_boxt[4], o_boxf, o_tri[kTriFields], o_trik, o_trin, o_trid, o_trih;
+    for (auto &o : o_box) o = take(nb * 4);
+    for (auto &o : o_boxt) o = take(nb * 4);
+    o_boxf = take(nb * 4);
+    for (auto &o : o_tri) o = take(nt * 4);
+    o_trik = take(nt * 4); o_trin = take(nt * 4); o_trid = take(nt * 4); o_trih = take(nt * 4);
+    const size_t o_ea = take(ne * 64), o_eb = take(ne * 64), o_ec = take(ne * 4), o_eo = take(ne * 4);
+    const size_t o_aa = take(na * 32), o_ab = take(na * 32), o_ac = take(na * 4), o_ad = take(na * 4), o_an = take(na * 4);
+    rc = grow(ctx->d_stage, ctx->stage_bytes, total);
+    if (rc != RT_DP_OK) return rc;
+    char *base = ctx->d_stage;
+    auto F = [&](size_t o) { return reinterpret_cast<float *>(base + o); };
+    auto U = [&](size_t o) { return reinterpret_cast<uint32_t *>(base + o); };
+
+    rt_dp_op_batch ob;
+    rt_dp_result_batch rb;
+    memset(&ob, 0, sizeof ob);
+    memset(&rb, 0, sizeof rb);
+    ob.struct_size = sizeof ob; rb.struct_size = sizeof rb;
+    ob.flags = RT_DP_F_DEVICE_PTRS;
+    ob.n[0] = nt; ob.n[1] = nb; ob.n[2] = ne; ob.n[3] = na;
+    for (int a = 0; a < 3; ++a) { ob.box.org[a] = F(o_box[a]); ob.box.dir[a] = F(o_box[3 + a]); ob.box.inv[a] = F(o_box[6 + a]); }
+    ob.box.extent = F(o_box[9]);
+    for (int b = 0; b < 4; ++b)
+        for (int f = 0; f < 6; ++f) ob.box.aabb[b][f] = F(o_box[10 + 6 * b + f]);
+    for (int k = 0; k < 4; ++k) rb.box.tmin_out[k] = F(o_boxt[k]);
+    rb.box.flags = U(o_boxf);
+    for (int a = 0; a < 3; ++a) { ob.tri.org[a] = F(o_tri[a]); ob.tri.shear[a] = F(o_tri[3 + a]); }
+    for (int v = 0; v < 3; ++v)
+        for (int a = 0; a < 3; ++a) ob.tri.vtx[v][a] = F(o_tri[6 + 3 * v + a]);
+    ob.tri.k = U(o_trik);
+    rb.tri.t_num = F(o_trin); rb.tri.t_denom = F(o_trid); rb.tri.hit = U(o_trih);
+    ob.euc.a = F(o_ea); ob.euc.b = F(o_eb); ob.euc.ctl = U(o_ec); rb.euc.accumulator = F(o_eo);
+    ob.ang.a = F(o_aa); ob.ang.b = F(o_ab); ob.ang.ctl = U(o_ac); rb.ang.dot_product = F(o_ad); rb.ang.norm = F(o_an);
+
+    BoxArgs ba;
+    TriArgs ta;
+    fill_box(ba, ob.box, rb.box);
+    fill_tri(ta, ob.tri, rb.tri);
+    VecArgs ea{ob.euc.a, ob.euc.b, ob.euc.ctl, rb.euc.accumulator, nullptr, nullptr, nullptr};
+    VecArgs aa{ob.ang.a, ob.ang.b, ob.ang.ctl, rb.ang.dot_product, rb.ang.norm, nullptr, nullptr};
+    HIP_TRY(stream_scatter(in_words, n, blockcnt, slot, ba, ta, ea, aa, s));
+    rc = launch_device(ctx, &ob, &rb, s);
+    if (rc != RT_DP_OK) return rc;
+    HIP_TRY(stream_gather(slot, n, ba, ta, ea, aa, ctx->extended ? 1 : 0, reinterpret_cast<uint32_t *>(d_out), s));
+    HIP_TRY(hipStreamSynchronize(s));
     return RT_DP_OK;
 }
 

@@ -56,6 +56,13 @@ hipError_t launch_tri(const TriArgs &args, uint64_t n, const Tuning &t, hipStrea
 hipError_t launch_euclid(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
 hipError_t launch_angular(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
 
+// Stream front-end (stream.hip): device-side stable partition of record streams by opcode.
+hipError_t stream_count_scan(const uint32_t *in, uint64_t n, uint32_t *blockcnt, uint32_t *totals_and_flag, hipStream_t s);
+hipError_t stream_scatter(const uint32_t *in, uint64_t n, const uint32_t *blockoff, uint32_t *slot, const BoxArgs &box, const TriArgs &tri,
+                          const VecArgs &euc, const VecArgs &ang, hipStream_t s);
+hipError_t stream_gather(const uint32_t *slot, uint64_t n, const BoxArgs &box, const TriArgs &tri, const VecArgs &euc, const VecArgs &ang,
+                         int extended, uint32_t *out, hipStream_t s);
+
 hipError_t launch_ray_prepare(const RayPrepArgs &args, uint64_t n, hipStream_t stream);
 
 // Exact top-16 nearest points per query under the datapath's Euclidean beat (dim 16).

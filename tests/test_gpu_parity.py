@@ -261,3 +261,46 @@ def test_ray_prepare_follows_sw_ray(ctx, torch_cuda):
     for c in range(3):
         assert (os_[c].cpu().numpy().view(u32)[finite] == canon(shear[:, c])[finite]).all(), "shear[%d]" % c
     assert (oe.cpu().numpy() == 4000.0).all()
+
+
+def _mixed_stream(seed, nb, nt, pe, pa, edge=0.3):
+    rng = np.random.default_rng(seed)
+    wb = gen.aos_from_box(gen.box_ops(nb, seed=seed + 1, edge_frac=edge))
+    wt = gen.aos_from_tri(*gen.tri_ops(nt, seed=seed + 2, edge_frac=edge))
+    a, b, ctl, _ = gen.vec_beats(pe, 16, seed=seed + 3, edge_frac=0.1)
+    we = gen.aos_from_vec(a, b, ctl, 2)
+    q, c, ctl8, _ = gen.vec_beats(pa, 8, seed=seed + 4, edge_frac=0.1)
+    wa = gen.aos_from_vec(q, c, ctl8, 3)
+    srcs = (wb, wt, we, wa)
+    tags = np.concatenate([np.full(w.shape[0], i) for i, w in enumerate(srcs)])
+    rng.shuffle(tags)
+    stream = np.zeros((tags.size, 84), u32)
+    for i in range(4):  # each opcode keeps its internal order
+        stream[tags == i] = srcs[i]
+    stream[stream[:, 0] < 2, 83] = 1
+    return stream
+
+
+@pytest.mark.parametrize("sizes", [(1, 0, 0, 0), (0, 0, 1, 0), (3, 2, 1, 1), (300, 300, 40, 40), (20000, 20000, 3000, 3000)])
+@pytest.mark.parametrize("extended", [True, False])
+def test_device_record_stream_matches_rtl_oracle(oracle, torch_cuda, sizes, extended):
+    """rt_dp_eval_bundles_device: on-device opcode partition + evaluation + re-assembly, against oracle A."""
+    torch = torch_cuda
+    stream = _mixed_stream(60 + sizes[0], *sizes)
+    c = capi.Context(support_euclidean=16 if extended else 0)
+    d_in = torch.from_numpy(stream.view(np.int32)).cuda()
+    d_out = torch.full((stream.shape[0], 21), -1, dtype=torch.int32, device="cuda")
+    c.eval_bundles_device(d_in, d_out)
+    want, state = oracle.eval_bundles("A" if stream.shape[0] < 5000 else "B", stream.view(oracle.IN_BUNDLE).reshape(-1), extended=extended)
+    assert_bits_equal(d_out.cpu().numpy().view(u32), want.view(u32).reshape(-1, 21), "output bundles")
+    if extended:
+        assert tuple(int(x) for x in c.get_accum().view(u32)) == state
+    # the host-partitioned entry point agrees
+    c.reset()
+    assert_bits_equal(c.eval_bundles(stream), want.view(u32).reshape(-1, 21), "host-partitioned output bundles")
+    bad = stream.copy()
+    bad[0, 0] = 7
+    with pytest.raises(capi.RtDpError) as e:
+        c.eval_bundles_device(torch.from_numpy(bad.view(np.int32)).cuda(), d_out)
+    assert e.value.code == capi.EOPCODE
+    c.close()
