@@ -22,6 +22,10 @@ for wl in box tri euclid angular; do
     run "fetch_$wl" 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_$wl" -- $BENCH --only $wl --steps 3 --warmup 1
     run "write_$wl" 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_$wl" -- $BENCH --only $wl --steps 3 --warmup 1
 done
+for wl in box tri euclid angular; do
+    run "valu_$wl" 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d "$OUT/pmc_valu_$wl" -- $BENCH --only $wl --steps 3 --warmup 1
+    run "grbm_$wl" 120 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_grbm_$wl" -- $BENCH --only $wl --steps 3 --warmup 1
+done
 run fetch_membench 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_membench" -- "$ROOT/raytracer_amd/lib/membench" 1024
 run write_membench 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_membench" -- "$ROOT/raytracer_amd/lib/membench" 1024
 echo "profile passes done" | tee -a "$OUT/log.txt"

@@ -116,6 +116,35 @@ for op, (prefix, total, rd, wr) in UNITS.items():
     traffic[op] = {"hbm_bytes_per_unit": round(fb + wb, 2), "fetched": round(fb, 2), "written": round(wb, 2),
                    "algorithmic": total, "units": n, "kernel": key[0]}
     lines.append("| %s | `%s` | %d | %.2f (%d) | %.2f (%d) | %.2f (%d) |" % (op, key[0], n, fb, rd, wb, wr, fb + wb, total))
+# ---- VALU issue and clock
+def pmc_timed(pattern, counter, prefix):
+    vals, durs = [], []
+    for r in rows(pattern):
+        k = short(r["Kernel_Name"])
+        if k and k.startswith(prefix) and r["Counter_Name"] == counter:
+            vals.append((int(r["Grid_Size"]), float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    if not vals:
+        return None
+    g = max(v[0] for v in vals)
+    vals = [v for v in vals if v[0] == g]
+    return med([v[1] for v in vals]), med([v[2] for v in vals])
+
+
+PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9 / 2  # 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles: 39.3 T lane-ops/s un-packed, un-fused
+lines += ["\n## VALU issue and clock (own counter passes: `--pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES`, `--pmc GRBM_GUI_ACTIVE`)\n",
+          "VALU fraction = SQ_INSTS_VALU x 64 lanes / kernel time / 39.3 T lane-ops/s (one un-packed wave64 instruction per SIMD-32 per 2 cycles; a packed"
+          " v_pk_* instruction counts once).  Clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time.\n",
+          "| opcode | VALU instructions per wave | per unit of work | VALU issue fraction | clock under the kernel |\n|---|---|---|---|---|"]
+for op, (prefix, total, rd, wr) in UNITS.items():
+    iv = pmc_timed("pmc_valu_%s/*/*counter_collection.csv" % op, "SQ_INSTS_VALU", prefix)
+    wv = pmc_timed("pmc_valu_%s/*/*counter_collection.csv" % op, "SQ_WAVES", prefix)
+    gr = pmc_timed("pmc_grbm_%s/*/*counter_collection.csv" % op, "GRBM_GUI_ACTIVE", prefix)
+    if not iv or not wv or op not in units_log:
+        continue
+    frac = iv[0] * 64 / (iv[1] * 1e-9) / PEAK_LANE_OPS
+    clk = (gr[0] / 8 / (gr[1] * 1e-9) / 1e9) if gr else float("nan")
+    lines.append("| %s | %.0f | %.1f | %.3f | %.2f GHz |" % (op, iv[0] / wv[0], iv[0] * 64 / units_log[op], frac, clk))
+    traffic[op]["valu_issue_fraction"] = round(frac, 4)
 open(os.path.join(PROF, tag + "_pmc.md"), "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(os.path.join(PROF, "traffic.json"), "w"), indent=1, sort_keys=True)
 print("\n".join(lines))
