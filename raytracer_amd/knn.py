@@ -67,10 +67,10 @@ def all_gather_merge(keys, k=TOPK, group=None):
     return merge_keys(gathered.view(world, m, kk), k)
 
 
-def search(ctx, points_shard, queries, index_base, k=TOPK, group=None, local_fn=None):
+def search(ctx, points_shard, queries, index_base, k=TOPK, group=None, local_fn=None, splits=None):
     """Sharded exact k-NN.  Returns (distances [m, k] float32, indices [m, k] int64), identical on every rank.
 
     local_fn replaces the GPU kernel in CPU rehearsals of the exchange (tests only)."""
-    fn = local_fn if local_fn is not None else (lambda p, q, base: local_topk(ctx, p, q, base, k=k))
+    fn = local_fn if local_fn is not None else (lambda p, q, base: local_topk(ctx, p, q, base, splits=splits, k=k))
     keys = fn(points_shard, queries, index_base)
     return unpack_keys(all_gather_merge(keys, k, group))

@@ -130,10 +130,11 @@ def pmc_timed(pattern, counter, prefix):
     return med([v[1] for v in vals]), med([v[2] for v in vals])
 
 
-PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9 / 2  # 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles: 39.3 T lane-ops/s un-packed, un-fused
+PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 2  # 256 CUs x 4 SIMD-32: one wave64 VALU instruction per SIMD per 2 cycles at 2.4 GHz
 lines += ["\n## VALU issue and clock (own counter passes: `--pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES`, `--pmc GRBM_GUI_ACTIVE`)\n",
-          "VALU fraction = SQ_INSTS_VALU x 64 lanes / kernel time / 39.3 T lane-ops/s (one un-packed wave64 instruction per SIMD-32 per 2 cycles; a packed"
-          " v_pk_* instruction counts once).  Clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time.\n",
+          "VALU issue fraction = SQ_INSTS_VALU / kernel time / 1.229 T wave-instructions/s (256 CUs x 4 SIMD-32, one wave64 instruction per 2 cycles,"
+          " 2.4 GHz; the FP32 vector peak of 157.3 TFLOP/s is this rate x 64 lanes x 2 flops of an FMA).  A packed v_pk_add_f32 / v_pk_mul_f32 counts as one"
+          " instruction here but occupies the SIMD like two, so the fraction understates kernels that use them.  Clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time.\n",
           "| opcode | VALU instructions per wave | per unit of work | VALU issue fraction | clock under the kernel |\n|---|---|---|---|---|"]
 for op, (prefix, total, rd, wr) in UNITS.items():
     iv = pmc_timed("pmc_valu_%s/*/*counter_collection.csv" % op, "SQ_INSTS_VALU", prefix)
@@ -141,7 +142,7 @@ for op, (prefix, total, rd, wr) in UNITS.items():
     gr = pmc_timed("pmc_grbm_%s/*/*counter_collection.csv" % op, "GRBM_GUI_ACTIVE", prefix)
     if not iv or not wv or op not in units_log:
         continue
-    frac = iv[0] * 64 / (iv[1] * 1e-9) / PEAK_LANE_OPS
+    frac = iv[0] / (iv[1] * 1e-9) / PEAK_WAVE_INSTS
     clk = (gr[0] / 8 / (gr[1] * 1e-9) / 1e9) if gr else float("nan")
     lines.append("| %s | %.0f | %.1f | %.3f | %.2f GHz |" % (op, iv[0] / wv[0], iv[0] * 64 / units_log[op], frac, clk))
     traffic[op]["valu_issue_fraction"] = round(frac, 4)
