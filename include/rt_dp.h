@@ -285,6 +285,37 @@ int rt_dp_ray_prepare(rt_dp_ctx *ctx, const rt_dp_ray_prep *rays, uint64_t n, vo
 int rt_dp_knn_euclid16(rt_dp_ctx *ctx, const float *points, uint32_t n_points, const float *queries, uint32_t n_queries,
                        uint32_t index_base, uint32_t splits, float *out_dist, uint32_t *out_idx, void *hip_stream);
 
+/* The same search through a tree over the points (no counterpart in the reference, as
+ * above).  The caller supplies a balanced partition of the points into n_leaves (a power of
+ * two) leaves of leaf_size slots (a multiple of 4), stored leaf by leaf:
+ *   points  [n_leaves * leaf_size][16]   pad slots hold +Inf in every coordinate
+ *   index   [n_leaves * leaf_size]       the index reported for the slot, 0xFFFFFFFF for a pad
+ *   leaf_lo / leaf_hi [n_leaves][16]     bounding box of the leaf's points; a dimension in
+ *                                        which a point of the leaf is NaN must be (-Inf, +Inf)
+ * (raytracer_amd/knn_tree.py builds this from a point set with a median-split k-d tree).
+ * queries [n_queries][16]; home_leaf[n_queries] names, per query, the leaf from which its walk
+ * starts (any leaf is valid; the leaf the query falls into prunes best, and queries should be
+ * sorted by it, because 64 consecutive queries walk together).  `splits` (a power of two,
+ * <= n_leaves) spreads the leaves of one query over that many workgroups; bound[n_queries]
+ * is scratch the call initialises.  out_dist / out_idx are [splits][n_queries][16] as for
+ * rt_dp_knn_euclid16, and merge the same way.  Leaves are skipped only when a lower bound on
+ * the distance to their box proves that none of their points can enter the list, so the
+ * merged result is bit-identical to rt_dp_knn_euclid16 on the same points.  Device pointers;
+ * asynchronous on `hip_stream` (NULL = context stream).                                  */
+typedef struct rt_dp_knn_tree {
+    uint32_t        struct_size;
+    uint32_t        n_leaves;
+    uint32_t        leaf_size;
+    uint32_t        reserved;
+    const float    *points;
+    const uint32_t *index;
+    const float    *leaf_lo;
+    const float    *leaf_hi;
+} rt_dp_knn_tree;
+
+int rt_dp_knn_tree_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, const float *queries, const uint32_t *home_leaf,
+                            uint32_t n_queries, uint32_t splits, uint32_t *bound, float *out_dist, uint32_t *out_idx, void *hip_stream);
+
 /* ---- tuning and diagnostics ---------------------------------------------------
  * Kernel-shape knobs (0 = library default), for A/B measurements; results do not
  * depend on them.  ops_per_lane: consecutive box / triangle ops one lane owns

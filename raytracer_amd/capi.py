@@ -109,8 +109,13 @@ class OutputBundle(C.Structure):
 
 assert C.sizeof(InputBundle) == 84 * 4 and C.sizeof(OutputBundle) == 21 * 4
 
+
+class KnnTree(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_leaves", C.c_uint32), ("leaf_size", C.c_uint32), ("reserved", C.c_uint32),
+                ("points", C.c_void_p), ("index", C.c_void_p), ("leaf_lo", C.c_void_p), ("leaf_hi", C.c_void_p)]
+
 EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize",
-           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
+           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_knn_tree_euclid16", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
            "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
 
 
@@ -149,6 +154,7 @@ def load():
     L.rt_dp_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.rt_dp_ray_prepare.argtypes = [vp, C.POINTER(RayPrep), C.c_uint64, vp]
     L.rt_dp_knn_euclid16.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
+    L.rt_dp_knn_tree_euclid16.argtypes = [vp, C.POINTER(KnnTree), vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     L.rt_dp_last_error.restype = C.c_char_p
     L.rt_dp_version.restype = C.c_char_p
     for name in EXPORTS:
@@ -337,6 +343,20 @@ class Context:
         assert tuple(out_dist.shape) == (splits, m, 16) and tuple(out_idx.shape) == (splits, m, 16)
         _check(self._L.rt_dp_knn_euclid16(self._h, points.data_ptr(), n, queries.data_ptr(), m, index_base, splits,
                                           out_dist.data_ptr(), out_idx.data_ptr(), C.c_void_p(stream) if stream else None))
+
+    def knn_tree_euclid16(self, tree, queries, home_leaf, bound, out_dist, out_idx, splits=1, stream=None):
+        """Tree-pruned top-16 (torch CUDA tensors).  tree: raytracer_amd.knn_tree.KnnTree; queries [m,16] float32 sorted by
+        home_leaf [m] int32; bound [m] int32 scratch; out_dist / out_idx [splits,m,16].  Asynchronous."""
+        for t in (queries, home_leaf, bound, out_dist, out_idx, tree.points, tree.index, tree.leaf_lo, tree.leaf_hi):
+            if not (t.is_cuda and t.is_contiguous()):
+                raise ValueError("knn_tree_euclid16 needs contiguous CUDA tensors")
+        m = int(queries.shape[0])
+        assert tuple(out_dist.shape) == (splits, m, 16) and tuple(out_idx.shape) == (splits, m, 16)
+        assert home_leaf.shape[0] == m and bound.shape[0] == m
+        ct = KnnTree(C.sizeof(KnnTree), tree.n_leaves, tree.leaf_size, 0, tree.points.data_ptr(), tree.index.data_ptr(),
+                     tree.leaf_lo.data_ptr(), tree.leaf_hi.data_ptr())
+        _check(self._L.rt_dp_knn_tree_euclid16(self._h, C.byref(ct), queries.data_ptr(), home_leaf.data_ptr(), m, splits, bound.data_ptr(),
+                                               out_dist.data_ptr(), out_idx.data_ptr(), C.c_void_p(stream) if stream else None))
 
     def eval_bundles(self, in_bundles):
         """in_bundles: numpy structured array whose itemsize equals sizeof(rt_dp_input_bundle)

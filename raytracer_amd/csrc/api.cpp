@@ -519,13 +519,42 @@ int rt_dp_knn_euclid16(rt_dp_ctx *ctx, const float *points, uint32_t n_points, c
     if (!queries || !out_dist || !out_idx || (n_points && !points)) return fail(RT_DP_ENULL, "rt_dp_knn_euclid16: NULL array");
     if (splits == 0 || splits > 65535u) return fail(RT_DP_EINVAL, "splits must be 1..65535");
     if ((uint64_t)index_base + n_points > 0xFFFFFFFFull) return fail(RT_DP_EINVAL, "index_base + n_points exceeds the 32-bit index range");
-    if ((reinterpret_cast<uintptr_t>(points) | reinterpret_cast<uintptr_t>(queries) | reinterpret_cast<uintptr_t>(out_dist) |
-         reinterpret_cast<uintptr_t>(out_idx)) & 3u)
-        return fail(RT_DP_EALIGN, "rt_dp_knn_euclid16: arrays must be 4-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(points) | reinterpret_cast<uintptr_t>(queries)) & 7u)
+        return fail(RT_DP_EALIGN, "rt_dp_knn_euclid16: points and queries must be 8-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(out_dist) | reinterpret_cast<uintptr_t>(out_idx)) & 3u)
+        return fail(RT_DP_EALIGN, "rt_dp_knn_euclid16: output arrays must be 4-byte aligned");
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
     HIP_TRY(launch_knn_euclid16(points, n_points, queries, n_queries, index_base, splits, out_dist, out_idx,
                                 hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
+    return RT_DP_OK;
+}
+
+int rt_dp_knn_tree_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, const float *queries, const uint32_t *home_leaf,
+                            uint32_t n_queries, uint32_t splits, uint32_t *bound, float *out_dist, uint32_t *out_idx, void *hip_stream) {
+    if (!ctx || !tree) return fail(RT_DP_ENULL, "rt_dp_knn_tree_euclid16: NULL argument");
+    if (tree->struct_size != sizeof(rt_dp_knn_tree)) return fail(RT_DP_EINVAL, "rt_dp_knn_tree.struct_size does not match this library");
+    if (n_queries == 0) return RT_DP_OK;
+    if (!queries || !home_leaf || !bound || !out_dist || !out_idx || !tree->points || !tree->index || !tree->leaf_lo || !tree->leaf_hi)
+        return fail(RT_DP_ENULL, "rt_dp_knn_tree_euclid16: NULL array");
+    const uint32_t nl = tree->n_leaves, ls = tree->leaf_size;
+    if (nl == 0 || (nl & (nl - 1))) return fail(RT_DP_EINVAL, "n_leaves = %u is not a power of two", nl);
+    if (ls == 0 || (ls & 3u)) return fail(RT_DP_EINVAL, "leaf_size = %u is not a positive multiple of 4", ls);
+    if ((uint64_t)nl * ls > 0xFFFFFFFFull) return fail(RT_DP_EINVAL, "n_leaves * leaf_size exceeds the 32-bit slot range");
+    if (splits == 0 || (splits & (splits - 1)) || splits > nl || splits > 65535u)
+        return fail(RT_DP_EINVAL, "splits = %u must be a power of two not above n_leaves", splits);
+    if ((reinterpret_cast<uintptr_t>(tree->points) | reinterpret_cast<uintptr_t>(tree->leaf_lo) | reinterpret_cast<uintptr_t>(tree->leaf_hi) |
+         reinterpret_cast<uintptr_t>(queries)) & 7u)
+        return fail(RT_DP_EALIGN, "rt_dp_knn_tree_euclid16: coordinate arrays must be 8-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(tree->index) | reinterpret_cast<uintptr_t>(home_leaf) | reinterpret_cast<uintptr_t>(bound) |
+         reinterpret_cast<uintptr_t>(out_dist) | reinterpret_cast<uintptr_t>(out_idx)) & 3u)
+        return fail(RT_DP_EALIGN, "rt_dp_knn_tree_euclid16: arrays must be 4-byte aligned");
+    uint32_t log2_splits = 0;
+    while ((1u << log2_splits) < splits) ++log2_splits;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
+    HIP_TRY(launch_knn_tree16(tree->points, tree->index, tree->leaf_lo, tree->leaf_hi, nl, ls, queries, home_leaf, n_queries, log2_splits, bound,
+                              out_dist, out_idx, hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
     return RT_DP_OK;
 }
 

@@ -67,12 +67,16 @@ __device__ __forceinline__ void knn_insert(float (&bd)[kTopK], uint32_t (&bi)[kT
 // many lanes at once.  The list is the set of the 16 smallest (dist, idx) keys offered, so
 // the order in which candidates are inserted is irrelevant; a parked candidate only delays
 // the tightening of its lane's filter bound, never the result.  pd is NaN when empty.
-__device__ __forceinline__ void knn_offer(float (&bd)[kTopK], uint32_t (&bi)[kTopK], float &pd, uint32_t &pi, float dist, uint32_t idx) {
-    const bool pass = dist <= bd[kTopK - 1];  // one compare filters almost every candidate (false for NaN)
+// thr is the lane's filter bound: never below the distance of the 16th-best key that the
+// final list can hold, so dropping dist > thr loses nothing (dist == thr still passes: the
+// index decides).
+__device__ __forceinline__ void knn_offer(float (&bd)[kTopK], uint32_t (&bi)[kTopK], float &pd, uint32_t &pi, float &thr, float dist, uint32_t idx) {
+    const bool pass = dist <= thr;  // one compare filters almost every candidate (false for NaN)
     if (__any(pass)) {
         if (__any(pass && (pd == pd))) {
             knn_insert(bd, bi, pd, pi);
             pd = __uint_as_float(0x7FC00000u);
+            thr = (bd[kTopK - 1] < thr) ? bd[kTopK - 1] : thr;
         }
         pd = pass ? dist : pd;
         pi = pass ? idx : pi;
@@ -97,6 +101,7 @@ __global__ __launch_bounds__(256) void k_knn_euclid16(const float *__restrict__ 
     for (int j = 0; j < kTopK; ++j) { bd[j] = __uint_as_float(0x7F800000u); bi[j] = 0xFFFFFFFFu; }
     float pd = __uint_as_float(0x7FC00000u);  // parked candidate (none)
     uint32_t pi = 0;
+    float thr = __uint_as_float(0x7F800000u);
 
     const uint32_t j0 = blockIdx.y * pts_per_split;
     const uint32_t j1 = (j0 + pts_per_split < n_pts) ? j0 + pts_per_split : n_pts;
@@ -107,15 +112,118 @@ __global__ __launch_bounds__(256) void k_knn_euclid16(const float *__restrict__ 
 #pragma unroll
         for (int u = 0; u < kKnnUnroll; ++u) dist[u] = knn_pair(qv, p + u * 8);
 #pragma unroll
-        for (int u = 0; u < kKnnUnroll; ++u) knn_offer(bd, bi, pd, pi, dist[u], idx_base + j + u);
+        for (int u = 0; u < kKnnUnroll; ++u) knn_offer(bd, bi, pd, pi, thr, dist[u], idx_base + j + u);
     }
-    for (; j < j1; ++j) knn_offer(bd, bi, pd, pi, knn_pair(qv, reinterpret_cast<const f2v *>(pts) + (size_t)j * 8), idx_base + j);
+    for (; j < j1; ++j) knn_offer(bd, bi, pd, pi, thr, knn_pair(qv, reinterpret_cast<const f2v *>(pts) + (size_t)j * 8), idx_base + j);
     knn_insert(bd, bi, pd, pi);
     if (live) {
         const size_t o = ((size_t)blockIdx.y * n_qry + q) * kTopK;
 #pragma unroll
         for (int t = 0; t < kTopK; ++t) { out_d[o + t] = bd[t]; out_i[o + t] = bi[t]; }
     }
+}
+
+// ---- the same search through a tree over the points ---------------------------------
+// The points are stored leaf by leaf (a balanced k-d partition built by the caller: 2^D
+// leaves of `leaf_size` slots, pad slots at +Inf with index 0xFFFFFFFF) with one
+// 16-dimensional bounding box per leaf.  A wave (64 queries, sorted by home leaf so that
+// they are neighbours in space) walks the leaves nearest-subtree-first (home ^ t) and scans
+// a leaf only if some lane's lower bound on the distance to its box does not exceed that
+// lane's filter bound.  Whatever is scanned goes through the very same distance and list
+// code as the exhaustive kernel, so the result is bit-identical to it provided no pruned
+// leaf holds a point that belongs in a list:
+//   * in exact arithmetic  B = sum_d max(lo_d - q_d, q_d - hi_d, 0)^2  <=  |q - p|^2  for
+//     every p in the box; the datapath's value of |q - p|^2 and the computed B each carry a
+//     relative rounding error below 2^-19 (at most 16 roundings on non-negative terms), and
+//     terms that underflow add at most 16 * 2^-126 absolutely; the test uses
+//     B * (1 - 2^-16) - 2^-122, which is therefore below every computed distance in the leaf;
+//   * a NaN in the bound arithmetic (Inf - Inf) reads as "no gap" (fmaxf drops it); boxes of
+//     leaves holding NaN coordinates are unbounded in that dimension (caller's contract).
+// blockIdx.y = s takes the leaves whose low log2(splits) index bits equal s: every split
+// starts next to the home leaf.  The splits of one query share their progress through
+// bound[q] (bits of a non-negative float, atomic min): it only ever holds the distance of
+// some list's 16th entry, an upper bound of the final 16th distance, so using it as the
+// filter bound changes how much is scanned, never what is found.
+struct KnnTreeArgs {
+    const float *pts;
+    const uint32_t *index;
+    const float *leaf_lo, *leaf_hi;
+    uint32_t n_leaves, leaf_size, log2_splits;
+};
+
+__global__ __launch_bounds__(256) void k_knn_tree16(KnnTreeArgs tree, const float *__restrict__ qry, const uint32_t *__restrict__ home,
+                                                   uint32_t n_qry, uint32_t *__restrict__ bound, float *__restrict__ out_d,
+                                                   uint32_t *__restrict__ out_i) {
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    const bool live = q < n_qry;
+    const uint32_t qq = live ? q : (n_qry - 1);
+    f2v qv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) qv[k] = reinterpret_cast<const f2v *>(qry)[(size_t)qq * 8 + k];
+
+    float bd[kTopK];
+    uint32_t bi[kTopK];
+#pragma unroll
+    for (int j = 0; j < kTopK; ++j) { bd[j] = __uint_as_float(0x7F800000u); bi[j] = 0xFFFFFFFFu; }
+    float pd = __uint_as_float(0x7FC00000u);
+    uint32_t pi = 0;
+    float thr = __uint_as_float(0x7F800000u);
+    float published = thr;
+
+    const uint32_t split = blockIdx.y;
+    const uint32_t per_split = tree.n_leaves >> tree.log2_splits;
+    const uint32_t hh = __builtin_amdgcn_readfirstlane(home[qq]) >> tree.log2_splits;  // the wave follows its first query
+    const f2v *pts2 = reinterpret_cast<const f2v *>(tree.pts);
+
+    for (uint32_t t = 0; t < per_split; ++t) {
+        const uint32_t leaf = ((hh ^ t) << tree.log2_splits) | split;  // wave-uniform
+        const f2v *lo = reinterpret_cast<const f2v *>(tree.leaf_lo) + (size_t)leaf * 8;
+        const f2v *hi = reinterpret_cast<const f2v *>(tree.leaf_hi) + (size_t)leaf * 8;
+        const float shared = __uint_as_float(__hip_atomic_load(bound + qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        float lb = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f2v a = lo[k] - qv[k], b = qv[k] - hi[k];
+            const float gx = fmaxf(fmaxf(a.x, b.x), 0.0f), gy = fmaxf(fmaxf(a.y, b.y), 0.0f);
+            lb += gx * gx;
+            lb += gy * gy;
+        }
+        thr = (shared < thr) ? shared : thr;
+        const float lbd = lb * 0.9999847412109375f - 1.8807909613156600e-37f;  // (1 - 2^-16), 2^-122
+        if (!__any(lbd <= thr)) continue;
+
+        const f2v *p = pts2 + (size_t)leaf * tree.leaf_size * 8;
+        const uint32_t *ix = tree.index + (size_t)leaf * tree.leaf_size;
+        for (uint32_t j = 0; j < tree.leaf_size; j += kKnnUnroll) {
+            float dist[kKnnUnroll];
+#pragma unroll
+            for (int u = 0; u < kKnnUnroll; ++u) dist[u] = knn_pair(qv, p + (size_t)(j + u) * 8);
+#pragma unroll
+            for (int u = 0; u < kKnnUnroll; ++u) knn_offer(bd, bi, pd, pi, thr, dist[u], ix[j + u]);
+        }
+        if (live && bd[kTopK - 1] < published) {
+            published = bd[kTopK - 1];
+            atomicMin(bound + q, __float_as_uint(published));
+        }
+    }
+    knn_insert(bd, bi, pd, pi);
+    if (live) {
+        const size_t o = ((size_t)blockIdx.y * n_qry + q) * kTopK;
+#pragma unroll
+        for (int t = 0; t < kTopK; ++t) { out_d[o + t] = bd[t]; out_i[o + t] = bi[t]; }
+    }
+}
+
+hipError_t launch_knn_tree16(const float *pts, const uint32_t *index, const float *leaf_lo, const float *leaf_hi, uint32_t n_leaves,
+                             uint32_t leaf_size, const float *qry, const uint32_t *home, uint32_t n_qry, uint32_t log2_splits,
+                             uint32_t *bound, float *out_d, uint32_t *out_i, hipStream_t stream) {
+    if (n_qry == 0) return hipSuccess;
+    hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(bound), 0x7F800000, n_qry, stream);  // +Inf: nothing known yet
+    if (e != hipSuccess) return e;
+    KnnTreeArgs tree{pts, index, leaf_lo, leaf_hi, n_leaves, leaf_size, log2_splits};
+    dim3 grid((n_qry + 255) / 256, 1u << log2_splits);
+    hipLaunchKernelGGL(k_knn_tree16, grid, dim3(256), 0, stream, tree, qry, home, n_qry, bound, out_d, out_i);
+    return hipGetLastError();
 }
 
 hipError_t launch_knn_euclid16(const float *pts, uint32_t n_pts, const float *qry, uint32_t n_qry, uint32_t idx_base,

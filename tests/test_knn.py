@@ -73,6 +73,91 @@ def test_knn_sharded_equals_unsharded(ctx, oracle, torch_cuda):
     assert (i.cpu().numpy() == want_i).all() and (d.cpu().numpy().view(np.uint32) == want_d.view(np.uint32)).all()
 
 
+def clustered_cloud(n, m, seed):
+    rng = np.random.default_rng(seed)
+    centres = rng.uniform(-1, 1, (12, 16)).astype(f32)
+    pts = (centres[rng.integers(0, 12, n)] + rng.normal(0, 0.05, (n, 16))).astype(f32)
+    qry = (centres[rng.integers(0, 12, m)] + rng.normal(0, 0.08, (m, 16))).astype(f32)
+    pts[n // 2:n // 2 + 40] = pts[7]      # 41 copies of one point: more ties than list slots
+    qry[2] = pts[7]
+    qry[3, 4] = np.nan                    # every distance NaN: an empty list
+    qry[4, 0] = np.inf
+    return pts, qry
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cloud,n,m,leaf,splits", [
+    ("uniform", 10, 5, 4, 1), ("uniform", 10, 5, 128, 1), ("uniform", 5000, 300, 64, 1), ("uniform", 5000, 300, 64, 4),
+    ("uniform", 40000, 1000, 128, None), ("clustered", 30000, 700, 32, 8), ("clustered", 30000, 700, 128, None),
+    ("lowdim", 50000, 600, 64, None)])
+def test_tree_search_equals_exhaustive_search(ctx, oracle, torch_cuda, cloud, n, m, leaf, splits):
+    """The pruned walk must return exactly what the exhaustive kernel returns (which the test above pins to the oracle)."""
+    torch = torch_cuda
+    from raytracer_amd import knn, knn_tree
+    if cloud == "uniform":
+        pts, qry = make_cloud(n, m, seed=n + m + leaf)
+    elif cloud == "clustered":
+        pts, qry = clustered_cloud(n, m, seed=leaf)
+    else:  # points on a 3-dimensional subspace: the tree prunes almost everything
+        rng = np.random.default_rng(9)
+        basis = rng.normal(0, 1, (3, 16))
+        pts = (rng.uniform(-1, 1, (n, 3)) @ basis).astype(f32)
+        qry = (rng.uniform(-1, 1, (m, 3)) @ basis).astype(f32)
+    P, Q = torch.from_numpy(pts).cuda(), torch.from_numpy(qry).cuda()
+    want = knn.local_topk(ctx, P, Q, 1000)
+    tree = knn_tree.KnnTree(P, leaf_size=leaf, index_base=1000)
+    got = knn_tree.local_topk(ctx, tree, Q, splits=splits)
+    assert torch.equal(got, want)
+    if n <= 5000:
+        wd, wi = oracle.knn_bruteforce(pts, qry, 16, 1000)
+        d, i = knn.unpack_keys(got)
+        assert (i.cpu().numpy() == wi).all() and (d.cpu().numpy().view(np.uint32) == wd.view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+def test_tree_argument_errors(ctx, torch_cuda):
+    torch = torch_cuda
+    from raytracer_amd import capi, knn_tree
+    P = torch.rand(1000, 16, device="cuda")
+    tree = knn_tree.KnnTree(P, leaf_size=64)
+    Q = torch.rand(10, 16, device="cuda")
+    h = torch.zeros(10, dtype=torch.int32, device="cuda")
+    b = torch.empty(10, dtype=torch.int32, device="cuda")
+    d = torch.empty(3, 10, 16, device="cuda")
+    i = torch.empty(3, 10, 16, dtype=torch.int32, device="cuda")
+    with pytest.raises(capi.RtDpError) as e:
+        ctx.knn_tree_euclid16(tree, Q, h, b, d, i, splits=3)
+    assert e.value.code == capi.EINVAL
+    tree.leaf_size = 6
+    with pytest.raises(capi.RtDpError):
+        ctx.knn_tree_euclid16(tree, Q, h, b, d[:1].contiguous(), i[:1].contiguous(), splits=1)
+
+
+def test_tree_build_is_a_balanced_partition():
+    import torch
+    from raytracer_amd import knn_tree
+    g = torch.Generator().manual_seed(4)
+    P = torch.rand(3000, 16, generator=g) * 2 - 1
+    P[17, 3] = float("nan")
+    tree = knn_tree.KnnTree(P, leaf_size=64, index_base=7)
+    assert tree.n_leaves == 64 and tree.points.shape == (64 * 64, 16)
+    idx = tree.index.to(torch.int64) & 0xFFFFFFFF
+    real = idx != knn_tree.PAD_INDEX
+    assert int(real.sum()) == 3000 and sorted(idx[real].tolist()) == list(range(7, 3007))  # a permutation of the points
+    assert torch.equal(torch.nan_to_num(tree.points[real], nan=123.0), torch.nan_to_num(P[(idx[real] - 7)], nan=123.0))
+    assert bool(torch.isinf(tree.points[~real]).all())
+    # every real point lies inside the box of its leaf; the NaN coordinate opened its box
+    lo = tree.leaf_lo.repeat_interleave(64, 0)[real]
+    hi = tree.leaf_hi.repeat_interleave(64, 0)[real]
+    pts = tree.points[real]
+    ok = ((pts >= lo) & (pts <= hi)) | torch.isnan(pts)
+    assert bool(ok.all())
+    leaf_of_nan = int(torch.nonzero(torch.isnan(tree.points).any(1))[0]) // 64
+    assert tree.leaf_lo[leaf_of_nan, 3] == float("-inf") and tree.leaf_hi[leaf_of_nan, 3] == float("inf")
+    home = tree.home_leaf(P[:200].nan_to_num(0.0))
+    assert int(home.min()) >= 0 and int(home.max()) < 64
+
+
 WORKER = r"""
 import sys
 import numpy as np, torch
