@@ -316,6 +316,43 @@ typedef struct rt_dp_knn_tree {
 int rt_dp_knn_tree_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, const float *queries, const uint32_t *home_leaf,
                             uint32_t n_queries, uint32_t splits, uint32_t *bound, float *out_dist, uint32_t *out_idx, void *hip_stream);
 
+/* ---- closest-hit traversal on the Quadbox and triangle ops ----------------------------
+ * No counterpart in the reference's sources, which end at the datapath: this is the loop a
+ * consumer runs around it.  The ops are those of UnifiedDatapath.scala (children sorted by
+ * entry distance with hits first, :1117-1132; triangle hit / t_num / t_denom, :1087-1116);
+ * the ray fields are derived as by rt_dp_ray_prepare.
+ *
+ * bvh: a 4-wide bounding volume hierarchy, root = node 0.
+ *   nodes [n_nodes][32] words: 0..23 the four child boxes (child b: min xyz at 6b, max xyz at
+ *     6b + 3; an absent child carries the all-+Inf box of SW_Data.scala:106-113), 24..27 the
+ *     four child references (uint32 images), 28..31 unused.  A reference is 0xFFFFFFFF (absent),
+ *     or a node index, or 0x80000000 | first_triangle << 3 | (count - 1) for a leaf of 1..8
+ *     consecutive triangles.  An inner child must have a larger index than its parent; this and
+ *     the range of every reference are checked on the device before the traversal starts
+ *     (RT_DP_EINVAL).
+ *   tris [n_tris][12] words: A xyz, B xyz, C xyz, 3 unused.
+ * Rays: origin[3], dir[3] as separate arrays of n_rays floats; `extent` is the initial ray
+ * extent (the reference's model uses 4000).  All of these are device pointers, 16-byte aligned.
+ *
+ * Level by level, every (ray, node) pair runs one Quadbox op with extent = min(`extent`, the
+ * ray's best t after the previous level); hit inner children form the next level, hit leaves
+ * run one triangle op per triangle.  A triangle hit with t = t_num / t_denom (IEEE division,
+ * -0 read as +0, NaN ignored) competes by (t, triangle index), smallest first.  out_t[i] /
+ * out_tri[i] receive the winner, or (+Inf, 0xFFFFFFFF).  The result is deterministic: it
+ * does not depend on scheduling.  stats (may be NULL) receives {levels, box ops, triangle ops,
+ * largest queue}.  Synchronous; work queues grow inside the context as needed.              */
+typedef struct rt_dp_bvh4 {
+    uint32_t     struct_size;
+    uint32_t     n_nodes;
+    uint32_t     n_tris;
+    uint32_t     reserved;
+    const float *nodes;
+    const float *tris;
+} rt_dp_bvh4;
+
+int rt_dp_trace_closest(rt_dp_ctx *ctx, const rt_dp_bvh4 *bvh, const float *const origin[3], const float *const dir[3],
+                        uint32_t n_rays, float extent, float *out_t, uint32_t *out_tri, uint64_t stats[4]);
+
 /* ---- tuning and diagnostics ---------------------------------------------------
  * Kernel-shape knobs (0 = library default), for A/B measurements; results do not
  * depend on them.  ops_per_lane: consecutive box / triangle ops one lane owns

@@ -110,12 +110,17 @@ class OutputBundle(C.Structure):
 assert C.sizeof(InputBundle) == 84 * 4 and C.sizeof(OutputBundle) == 21 * 4
 
 
+class Bvh4(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_nodes", C.c_uint32), ("n_tris", C.c_uint32), ("reserved", C.c_uint32),
+                ("nodes", C.c_void_p), ("tris", C.c_void_p)]
+
+
 class KnnTree(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_leaves", C.c_uint32), ("leaf_size", C.c_uint32), ("reserved", C.c_uint32),
                 ("points", C.c_void_p), ("index", C.c_void_p), ("leaf_lo", C.c_void_p), ("leaf_hi", C.c_void_p)]
 
 EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize",
-           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_knn_tree_euclid16", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
+           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_knn_tree_euclid16", "rt_dp_trace_closest", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
            "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
 
 
@@ -155,6 +160,8 @@ def load():
     L.rt_dp_ray_prepare.argtypes = [vp, C.POINTER(RayPrep), C.c_uint64, vp]
     L.rt_dp_knn_euclid16.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.rt_dp_knn_tree_euclid16.argtypes = [vp, C.POINTER(KnnTree), vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
+    L.rt_dp_trace_closest.argtypes = [vp, C.POINTER(Bvh4), C.POINTER(vp * 3), C.POINTER(vp * 3), C.c_uint32, C.c_float, vp, vp,
+                                      C.POINTER(C.c_uint64 * 4)]
     L.rt_dp_last_error.restype = C.c_char_p
     L.rt_dp_version.restype = C.c_char_p
     for name in EXPORTS:
@@ -357,6 +364,23 @@ class Context:
                      tree.leaf_lo.data_ptr(), tree.leaf_hi.data_ptr())
         _check(self._L.rt_dp_knn_tree_euclid16(self._h, C.byref(ct), queries.data_ptr(), home_leaf.data_ptr(), m, splits, bound.data_ptr(),
                                                out_dist.data_ptr(), out_idx.data_ptr(), C.c_void_p(stream) if stream else None))
+
+    def trace_closest(self, nodes, tris, origin, direction, extent, out_t, out_tri):
+        """Closest hit of every ray in a 4-wide hierarchy (torch CUDA tensors).  nodes [m,32] float32, tris [n,12] float32,
+        origin / direction: lists of three float32 tensors [r]; out_t float32 [r], out_tri int32 [r] (bit image of uint32).
+        Returns {levels, box_ops, tri_ops, widest_queue}.  Synchronous."""
+        for t in [nodes, tris, out_t, out_tri] + list(origin) + list(direction):
+            if not (t.is_cuda and t.is_contiguous()):
+                raise ValueError("trace_closest needs contiguous CUDA tensors")
+        r = int(origin[0].shape[0])
+        assert nodes.shape[1] == 32 and (tris.shape[0] == 0 or tris.shape[1] == 12) and out_t.shape[0] == r and out_tri.shape[0] == r
+        bvh = Bvh4(C.sizeof(Bvh4), int(nodes.shape[0]), int(tris.shape[0]), 0, nodes.data_ptr(), tris.data_ptr() if tris.shape[0] else None)
+        o = (C.c_void_p * 3)(*[t.data_ptr() for t in origin])
+        d = (C.c_void_p * 3)(*[t.data_ptr() for t in direction])
+        stats = (C.c_uint64 * 4)()
+        _check(self._L.rt_dp_trace_closest(self._h, C.byref(bvh), C.byref(o), C.byref(d), r, float(extent), out_t.data_ptr(), out_tri.data_ptr(),
+                                           C.byref(stats)))
+        return {"levels": stats[0], "box_ops": stats[1], "tri_ops": stats[2], "widest_queue": stats[3]}
 
     def eval_bundles(self, in_bundles):
         """in_bundles: numpy structured array whose itemsize equals sizeof(rt_dp_input_bundle)

@@ -54,6 +54,11 @@ struct rt_dp_ctx {
     // grow-only workspace of the device-side record stream path (slots, block offsets)
     char *d_stream = nullptr;
     size_t stream_bytes = 0;
+    // traversal driver: ray records + best[] + counters in d_trace, three work queues
+    char *d_trace = nullptr;
+    size_t trace_bytes = 0;
+    char *d_queue[3] = {nullptr, nullptr, nullptr};
+    size_t queue_items[3] = {0, 0, 0};
     Tuning tuning{0, 0, 0, 0, 0};
 };
 
@@ -320,6 +325,9 @@ void rt_dp_destroy(rt_dp_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_stream) (void)hipFree(ctx->d_stream);
+    if (ctx->d_trace) (void)hipFree(ctx->d_trace);
+    for (char *q : ctx->d_queue)
+        if (q) (void)hipFree(q);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (g_default_ctx == ctx) g_default_ctx = nullptr;
@@ -555,6 +563,110 @@ int rt_dp_knn_tree_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, const fl
     if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
     HIP_TRY(launch_knn_tree16(tree->points, tree->index, tree->leaf_lo, tree->leaf_hi, nl, ls, queries, home_leaf, n_queries, log2_splits, bound,
                               out_dist, out_idx, hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
+    return RT_DP_OK;
+}
+
+namespace {
+
+// Replaces a device buffer whose contents are dead by one of at least `want` bytes.
+int regrow(char *&buf, size_t &have, size_t want, const char *what) {
+    if (want <= have) return RT_DP_OK;
+    if (buf) { hipError_t e = hipFree(buf); buf = nullptr; have = 0; if (e != hipSuccess) return fail(RT_DP_EHIP, "hipFree: %s", hipGetErrorString(e)); }
+    hipError_t e = hipMalloc(&buf, want);
+    if (e != hipSuccess) return fail(RT_DP_ENOMEM, "hipMalloc(%zu) for %s failed: %s", want, what, hipGetErrorString(e));
+    have = want;
+    return RT_DP_OK;
+}
+
+}  // namespace
+
+int rt_dp_trace_closest(rt_dp_ctx *ctx, const rt_dp_bvh4 *bvh, const float *const origin[3], const float *const dir[3],
+                        uint32_t n_rays, float extent, float *out_t, uint32_t *out_tri, uint64_t stats[4]) {
+    if (!ctx || !bvh || !origin || !dir) return fail(RT_DP_ENULL, "rt_dp_trace_closest: NULL argument");
+    if (bvh->struct_size != sizeof(rt_dp_bvh4)) return fail(RT_DP_EINVAL, "rt_dp_bvh4.struct_size does not match this library");
+    if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    if (n_rays == 0) return RT_DP_OK;
+    if (!out_t || !out_tri || !bvh->nodes || (bvh->n_tris && !bvh->tris)) return fail(RT_DP_ENULL, "rt_dp_trace_closest: NULL array");
+    if (bvh->n_nodes == 0) return fail(RT_DP_EINVAL, "the hierarchy has no root node");
+    if (bvh->n_nodes >= 0x80000000u || bvh->n_tris > (1u << 28)) return fail(RT_DP_EINVAL, "hierarchy too large for 32-bit references");
+    uintptr_t acc = reinterpret_cast<uintptr_t>(bvh->nodes) | reinterpret_cast<uintptr_t>(bvh->tris);
+    for (int c = 0; c < 3; ++c) {
+        if (!origin[c] || !dir[c]) return fail(RT_DP_ENULL, "rt_dp_trace_closest: origin[] / dir[] is NULL");
+        acc |= reinterpret_cast<uintptr_t>(origin[c]) | reinterpret_cast<uintptr_t>(dir[c]);
+    }
+    if (acc & 15u) return fail(RT_DP_EALIGN, "rt_dp_trace_closest: nodes, tris and ray arrays must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(out_t) | reinterpret_cast<uintptr_t>(out_tri)) & 3u)
+        return fail(RT_DP_EALIGN, "rt_dp_trace_closest: output arrays must be 4-byte aligned");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipDeviceSynchronize());  // the caller's arrays may still be in flight on other streams
+
+    const size_t ray_bytes = (size_t)n_rays * 64, best_bytes = (size_t)n_rays * 8;
+    HIP_TRY(hipStreamSynchronize(s));
+    int rc = regrow(ctx->d_trace, ctx->trace_bytes, ray_bytes + best_bytes + 256, "ray records");
+    if (rc != RT_DP_OK) return rc;
+    float *rays = reinterpret_cast<float *>(ctx->d_trace);
+    unsigned long long *best = reinterpret_cast<unsigned long long *>(ctx->d_trace + ray_bytes);
+    uint32_t *counters = reinterpret_cast<uint32_t *>(ctx->d_trace + ray_bytes + best_bytes);
+    const size_t first_items = (size_t)n_rays + (size_t)n_rays / 2 + 1024;
+    for (int q = 0; q < 3; ++q) {
+        size_t bytes = ctx->queue_items[q] * 8;
+        rc = regrow(ctx->d_queue[q], bytes, first_items * 8, "work queue");
+        ctx->queue_items[q] = bytes / 8;
+        if (rc != RT_DP_OK) return rc;
+    }
+    {
+        uint32_t bad = 0;
+        HIP_TRY(hipMemsetAsync(counters, 0, 16, s));
+        HIP_TRY(trace_validate(bvh->nodes, bvh->n_nodes, bvh->n_tris, counters, s));
+        HIP_TRY(hipMemcpyAsync(&bad, counters, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (bad)
+            return fail(RT_DP_EINVAL, "node %u holds a child reference outside the hierarchy (inner children must have a larger index than their parent)", bad - 1);
+    }
+    int cur = 0, nxt = 1;
+    const int lf = 2;
+    HIP_TRY(trace_init(origin, dir, n_rays, extent, rays, best, ctx->d_queue[cur], s));
+    uint64_t count = n_rays, levels = 0, box_ops = 0, tri_ops = 0, widest = n_rays;
+    while (count) {
+        if (++levels > 4096) return fail(RT_DP_EINVAL, "the hierarchy is deeper than 4096 levels (a cycle in the child references?)");
+        uint32_t host[4];
+        for (;;) {  // repeated only when a queue turned out too small for this level
+            HIP_TRY(hipMemsetAsync(counters, 0, 16, s));
+            HIP_TRY(trace_box(ctx->d_queue[cur], (uint32_t)count, rays, bvh->nodes, best, ctx->d_queue[nxt], (uint32_t)ctx->queue_items[nxt],
+                              ctx->d_queue[lf], (uint32_t)ctx->queue_items[lf], counters, s));
+            HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (host[0] <= ctx->queue_items[nxt] && host[1] <= ctx->queue_items[lf]) break;
+            if (host[0] > ctx->queue_items[nxt]) {
+                size_t bytes = ctx->queue_items[nxt] * 8;
+                rc = regrow(ctx->d_queue[nxt], bytes, ((size_t)host[0] + host[0] / 4) * 8, "work queue");
+                ctx->queue_items[nxt] = bytes / 8;
+                if (rc != RT_DP_OK) return rc;
+            }
+            if (host[1] > ctx->queue_items[lf]) {
+                size_t bytes = ctx->queue_items[lf] * 8;
+                rc = regrow(ctx->d_queue[lf], bytes, ((size_t)host[1] + host[1] / 4) * 8, "leaf queue");
+                ctx->queue_items[lf] = bytes / 8;
+                if (rc != RT_DP_OK) return rc;
+            }
+        }
+        box_ops += count;
+        if (host[1]) {
+            HIP_TRY(trace_tri(ctx->d_queue[lf], host[1], rays, bvh->tris, best, counters, s));
+            HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            tri_ops += host[2];
+        }
+        count = host[0];
+        if (count > widest) widest = count;
+        if (host[1] > widest) widest = host[1];
+        const int t = cur; cur = nxt; nxt = t;
+    }
+    HIP_TRY(trace_finish(best, n_rays, out_t, out_tri, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (stats) { stats[0] = levels; stats[1] = box_ops; stats[2] = tri_ops; stats[3] = widest; }
     return RT_DP_OK;
 }
 

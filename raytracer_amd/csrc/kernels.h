@@ -69,6 +69,15 @@ hipError_t launch_ray_prepare(const RayPrepArgs &args, uint64_t n, hipStream_t s
 // out_d / out_i: [splits][n_qry][16], ascending by (distance, index); unused slots hold (+Inf, 0xFFFFFFFF).
 hipError_t launch_knn_euclid16(const float *pts, uint32_t n_pts, const float *qry, uint32_t n_qry, uint32_t idx_base,
                                uint32_t splits, float *out_d, uint32_t *out_i, hipStream_t stream);
+// traversal driver (trace.hip); queues hold (ray, node or leaf reference) pairs of 8 bytes
+hipError_t trace_validate(const float *nodes, uint32_t n_nodes, uint32_t n_tris, uint32_t *bad, hipStream_t s);
+hipError_t trace_init(const float *const origin[3], const float *const dir[3], uint32_t n, float extent, float *rays,
+                      unsigned long long *best, void *queue, hipStream_t s);
+hipError_t trace_box(const void *cur, uint32_t count, const float *rays, const float *nodes, const unsigned long long *best, void *next,
+                     uint32_t next_cap, void *leaf, uint32_t leaf_cap, uint32_t *counters, hipStream_t s);
+hipError_t trace_tri(const void *leaf, uint32_t count, const float *rays, const float *tris, unsigned long long *best, uint32_t *counters,
+                     hipStream_t s);
+hipError_t trace_finish(const unsigned long long *best, uint32_t n, float *out_t, uint32_t *out_tri, hipStream_t s);
 hipError_t launch_knn_tree16(const float *pts, const uint32_t *index, const float *leaf_lo, const float *leaf_hi, uint32_t n_leaves,
                              uint32_t leaf_size, const float *qry, const uint32_t *home, uint32_t n_qry, uint32_t log2_splits,
                              uint32_t *bound, float *out_d, uint32_t *out_i, hipStream_t stream);

@@ -1,0 +1,110 @@
+"""Closest-hit traversal driver: hierarchy construction (CPU) and the GPU wavefront loop against a
+CPU model assembled from the oracle's Quadbox / triangle ops."""
+import numpy as np
+import pytest
+
+from raytracer_amd import bvh
+
+f32, u32 = np.float32, np.uint32
+
+
+def test_bvh4_is_a_partition_with_enclosing_boxes():
+    tris = bvh.random_scene(3001, seed=1)
+    nodes, tris12, order = bvh.build_bvh4(tris, leaf_size=4)
+    assert sorted(order.tolist()) == list(range(3001)) and (tris12[:, :9] == tris[order]).all()
+    refs = nodes[:, 24:28].copy().view(u32)
+    seen = np.zeros(3001, bool)
+    for i in range(nodes.shape[0]):
+        for c in range(4):
+            r = int(refs[i, c])
+            box = nodes[i, 6 * c:6 * c + 6]
+            if r == bvh.NONE:
+                assert np.isinf(box).all() and (box > 0).all()
+                continue
+            if r & bvh.LEAF:
+                first, cnt = (r & 0x7FFFFFFF) >> 3, (r & 7) + 1
+                assert cnt <= 4 and not seen[first:first + cnt].any()
+                seen[first:first + cnt] = True
+                v = tris12[first:first + cnt, :9].reshape(-1, 3)
+                assert (v.min(0) == box[:3]).all() and (v.max(0) == box[3:]).all()
+            else:
+                assert i < r < nodes.shape[0]
+                child = nodes[r, :24].reshape(4, 6)
+                live = refs[r] != bvh.NONE
+                assert (child[live, :3].min(0) == box[:3]).all() and (child[live, 3:].max(0) == box[3:]).all()
+    assert seen.all()
+    one, t12, _ = bvh.build_bvh4(tris[:3], leaf_size=4)
+    r = one[0, 24:28].copy().view(u32)
+    assert one.shape[0] == 1 and sum(int(x & 7) + 1 for x in r if x != bvh.NONE) == 3  # a root of leaves
+
+
+def run_gpu(ctx, torch, nodes, tris12, org, dirs, extent):
+    dev = "cuda"
+    N, T = torch.from_numpy(nodes).to(dev), torch.from_numpy(tris12).to(dev)
+    o = [torch.from_numpy(np.ascontiguousarray(org[:, a])).to(dev) for a in range(3)]
+    d = [torch.from_numpy(np.ascontiguousarray(dirs[:, a])).to(dev) for a in range(3)]
+    t = torch.empty(org.shape[0], dtype=torch.float32, device=dev)
+    i = torch.empty(org.shape[0], dtype=torch.int32, device=dev)
+    stats = ctx.trace_closest(N, T, o, d, extent, t, i)
+    return t.cpu().numpy(), i.cpu().numpy().view(u32), stats
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_tris,n_rays,leaf,jitter,extent", [(1, 50, 4, 0.0, 4000.0), (37, 500, 1, 5.0, 4000.0), (5000, 20000, 4, 0.0, 4000.0),
+                                                              (5000, 20000, 8, 30.0, 4000.0), (20000, 50000, 2, 10.0, 900.0)])
+def test_trace_matches_the_oracle_model(ctx, oracle, torch_cuda, n_tris, n_rays, leaf, jitter, extent):
+    from trace_model import trace_closest
+    tris = bvh.random_scene(n_tris, seed=n_tris)
+    nodes, tris12, order = bvh.build_bvh4(tris, leaf_size=leaf)
+    org, dirs = bvh.rays_towards(tris, n_rays, seed=n_rays, jitter=jitter)
+    dirs[3] = 0.0                    # a degenerate ray: inv = Inf, 0 * Inf = NaN in the slab test
+    org[4] = np.nan
+    dirs[5, 1] = 0.0                 # axis-parallel component
+    want_t, want_i, want_stats = trace_closest(oracle, nodes, tris12, org, dirs, extent)
+    got_t, got_i, stats = run_gpu(ctx, torch_cuda, nodes, tris12, org, dirs, extent)
+    assert (got_i == want_i).all() and (got_t.view(u32) == want_t.view(u32)).all()
+    assert stats == want_stats
+    hit = got_i != 0xFFFFFFFF
+    assert hit.mean() > 0.15 or n_tris < 100  # rays aimed at triangles often hit (one winding only: the test culls back faces)
+    assert np.isinf(got_t[~hit]).all()
+
+
+@pytest.mark.gpu
+def test_trace_agrees_with_testing_every_triangle(ctx, oracle, torch_cuda):
+    """Sanity beyond parity: the hierarchy only skips triangles, it never invents hits, and with generous
+    boxes it finds what an exhaustive triangle test finds."""
+    tris = bvh.random_scene(600, seed=3)
+    nodes, tris12, order = bvh.build_bvh4(tris, leaf_size=4)
+    org, dirs = bvh.rays_towards(tris, 400, seed=4, jitter=2.0)
+    got_t, got_i, _ = run_gpu(ctx, torch_cuda, nodes, tris12, org, dirs, 4000.0)
+    from raytracer_amd import gen
+    inv, kx, ky, kz, shear = gen.ray_derived(dirs)
+    kw = gen.pack_k(kx, ky, kz)
+    r, t = np.repeat(np.arange(400), 600), np.tile(np.arange(600), 400)
+    num, den, hit = oracle.tri_soa([org[r, a] for a in range(3)] + [shear[r, a] for a in range(3)] + [tris12[t, w] for w in range(9)], kw[r])
+    with np.errstate(all="ignore"):
+        tt = np.where((hit != 0), num / den, np.inf).astype(f32).reshape(400, 600)
+    tt = np.where(np.isnan(tt) | (tt > 4000.0), np.inf, tt)
+    brute_i = np.where(np.isinf(tt.min(1)), 0xFFFFFFFF, tt.argmin(1)).astype(u32)
+    agree = (brute_i == got_i).mean()
+    assert agree > 0.97, agree
+    found = got_i != 0xFFFFFFFF
+    assert (tt[np.arange(400)[found], got_i[found].astype(np.int64)] == got_t[found]).all()  # every reported hit is a real one
+
+
+@pytest.mark.gpu
+def test_trace_rejects_a_broken_hierarchy(ctx, torch_cuda):
+    torch = torch_cuda
+    from raytracer_amd import capi
+    tris = bvh.random_scene(100, seed=5)
+    nodes, tris12, _ = bvh.build_bvh4(tris)
+    org, dirs = bvh.rays_towards(tris, 10)
+    bad = nodes.copy()
+    bad[1, 24:25] = np.array([0], u32).view(f32)      # a child pointing back at the root: a cycle
+    with pytest.raises(capi.RtDpError) as e:
+        run_gpu(ctx, torch, bad, tris12, org, dirs, 4000.0)
+    assert e.value.code == capi.EINVAL
+    bad = nodes.copy()
+    bad[0, 25:26] = np.array([bvh.leaf_ref(98, 4)], u32).view(f32)   # a leaf running past the triangle array
+    with pytest.raises(capi.RtDpError):
+        run_gpu(ctx, torch, bad, tris12, org, dirs, 4000.0)
