@@ -50,6 +50,9 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=10.0)
     p.add_argument("--knn-log2-points", type=int, default=20)
     p.add_argument("--knn-log2-queries", type=int, default=16)
+    p.add_argument("--trace-wavefront", type=int, default=0, help="1: breadth-first walk with queue compaction; 0: depth-first walk")
+    p.add_argument("--trace-log2-tris", type=int, default=18)
+    p.add_argument("--trace-log2-rays", type=int, default=22)
     p.add_argument("--knn-tree", type=int, default=1, help="1: walk the k-d tree index with box pruning; 0: exhaustive scan")
     p.add_argument("--knn-data", default="uniform", help="uniform: U(-1,1)^16 (the named configuration); clustered: 256 Gaussian clusters, sigma 0.05")
     p.add_argument("--knn-leaf", type=int, default=128, help="points per tree leaf")
@@ -298,6 +301,46 @@ def run_stream(a, world, rank, local, dev):
     dist_util.shutdown()
 
 
+def run_trace(a, world, rank, local, dev):
+    """Closest-hit traversal: 2^18 random triangles in a 4-wide hierarchy, 2^22 rays per GPU aimed at triangle
+    centroids (the reference's genRandomRayGivenPoint pattern); every rank traces its own rays (weak scaling)."""
+    from raytracer_amd import bvh
+    n_tris, n_rays = 1 << a.trace_log2_tris, 1 << a.trace_log2_rays
+    tris = bvh.random_scene(n_tris)
+    t0 = time.perf_counter()
+    nodes, tris12, _ = bvh.build_bvh4(tris, leaf_size=4)
+    build_s = time.perf_counter() - t0
+    org, dirs = bvh.rays_towards(tris, n_rays, seed=20241015 + rank)
+    N, T = torch.from_numpy(nodes).to(dev), torch.from_numpy(tris12).to(dev)
+    o = [torch.from_numpy(np.ascontiguousarray(org[:, c])).to(dev) for c in range(3)]
+    d = [torch.from_numpy(np.ascontiguousarray(dirs[:, c])).to(dev) for c in range(3)]
+    out_t = torch.empty(n_rays, dtype=torch.float32, device=dev)
+    out_i = torch.empty(n_rays, dtype=torch.int32, device=dev)
+    ctx = capi.Context(device=local)
+    torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        stats = ctx.trace_closest(N, T, o, d, 4000.0, out_t, out_i, wavefront=bool(a.trace_wavefront))
+    dist_util.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        stats = ctx.trace_closest(N, T, o, d, 4000.0, out_t, out_i, wavefront=bool(a.trace_wavefront))
+    torch.cuda.synchronize()
+    dist_util.barrier()
+    wall = dist_util.max_over_ranks(time.perf_counter() - t0, device="cuda")
+    if rank == 0:
+        per = wall / a.steps
+        hits = float((out_i != -1).float().mean().item())
+        print(json.dumps({"metric": "rays/s (closest hit, BVH4 %s traversal on the datapath ops)" % ("wavefront" if a.trace_wavefront else "depth-first"), "value": round(n_rays * world / per, 1),
+                          "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(per * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "trace: 2^%d triangles, 2^%d rays per GPU, leaf size 4, hierarchy built on the host in %.1f s (not timed)" % (
+                              a.trace_log2_tris, a.trace_log2_rays, build_s)},
+                          "per_call": {k: int(v) for k, v in stats.items()}, "hit_fraction": round(hits, 4),
+                          "box_ops_per_s": round(stats["box_ops"] / per, 1), "tri_ops_per_s": round(stats["tri_ops"] / per, 1)}), flush=True)
+    ctx.close()
+    dist_util.shutdown()
+
+
 def run_knn(a, world, rank, local, dev):
     """k-NN configuration: 2^20 points (sharded over the ranks), 2^16 queries (replicated), dim 16, k = 16;
     per-GPU partial lists merged after one all-gather.  Total work is fixed: strong scaling."""
@@ -370,6 +413,9 @@ def main():
         return
     if a.only == "knn":
         run_knn(a, world, rank, local, dev)
+        return
+    if a.only == "trace":
+        run_trace(a, world, rank, local, dev)
         return
 
     which = [a.only] if a.only else ["box", "tri", "euclid", "angular", "mixed"]

@@ -334,13 +334,24 @@ int rt_dp_knn_tree_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, const fl
  * Rays: origin[3], dir[3] as separate arrays of n_rays floats; `extent` is the initial ray
  * extent (the reference's model uses 4000).  All of these are device pointers, 16-byte aligned.
  *
- * Level by level, every (ray, node) pair runs one Quadbox op with extent = min(`extent`, the
- * ray's best t after the previous level); hit inner children form the next level, hit leaves
- * run one triangle op per triangle.  A triangle hit with t = t_num / t_denom (IEEE division,
- * -0 read as +0, NaN ignored) competes by (t, triangle index), smallest first.  out_t[i] /
- * out_tri[i] receive the winner, or (+Inf, 0xFFFFFFFF).  The result is deterministic: it
- * does not depend on scheduling.  stats (may be NULL) receives {levels, box ops, triangle ops,
- * largest queue}.  Synchronous; work queues grow inside the context as needed.              */
+ * Two walks, chosen by `flags`; both report, per ray, the smallest (t, triangle index) among
+ * the triangle hits they evaluate, t = t_num / t_denom (IEEE division, -0 read as +0, a NaN t
+ * ignored), or (+Inf, 0xFFFFFFFF).  Both are deterministic (independent of scheduling).
+ *   0 (depth first): one lane walks one ray with a stack.  Pop (reference, entry distance);
+ *     limit = min(extent, best t so far); drop the entry unless entry distance < limit; a leaf
+ *     runs one triangle op per triangle, in order; a node runs one Quadbox op with extent =
+ *     limit and pushes its hit children farthest first, so the closest is popped next.  At most
+ *     64 pending entries per ray (RT_DP_EINVAL beyond: roughly 21 levels of 4-wide nodes).
+ *   RT_DP_TRACE_WAVEFRONT (breadth first): level by level, every (ray, node) pair runs one
+ *     Quadbox op with extent = min(extent, the ray's best t after the previous level); hit inner
+ *     children form the next level (appended by ballot compaction of the sorted hit masks), hit
+ *     leaves run their triangle ops.  Visits every node the ray's extent reaches: the engine for
+ *     "all candidates" queries; work queues grow inside the context as needed.
+ * The two can differ only where a triangle's t and its box's entry distance round to
+ * different sides of each other.  stats (may be NULL) receives {levels (wavefront) or 0, box
+ * ops, triangle ops, largest queue (wavefront) or 0}.  Synchronous.                          */
+#define RT_DP_TRACE_WAVEFRONT 1u
+
 typedef struct rt_dp_bvh4 {
     uint32_t     struct_size;
     uint32_t     n_nodes;
@@ -351,7 +362,7 @@ typedef struct rt_dp_bvh4 {
 } rt_dp_bvh4;
 
 int rt_dp_trace_closest(rt_dp_ctx *ctx, const rt_dp_bvh4 *bvh, const float *const origin[3], const float *const dir[3],
-                        uint32_t n_rays, float extent, float *out_t, uint32_t *out_tri, uint64_t stats[4]);
+                        uint32_t n_rays, float extent, uint32_t flags, float *out_t, uint32_t *out_tri, uint64_t stats[4]);
 
 /* ---- tuning and diagnostics ---------------------------------------------------
  * Kernel-shape knobs (0 = library default), for A/B measurements; results do not

@@ -110,6 +110,9 @@ class OutputBundle(C.Structure):
 assert C.sizeof(InputBundle) == 84 * 4 and C.sizeof(OutputBundle) == 21 * 4
 
 
+TRACE_WAVEFRONT = 1
+
+
 class Bvh4(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_nodes", C.c_uint32), ("n_tris", C.c_uint32), ("reserved", C.c_uint32),
                 ("nodes", C.c_void_p), ("tris", C.c_void_p)]
@@ -160,7 +163,7 @@ def load():
     L.rt_dp_ray_prepare.argtypes = [vp, C.POINTER(RayPrep), C.c_uint64, vp]
     L.rt_dp_knn_euclid16.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.rt_dp_knn_tree_euclid16.argtypes = [vp, C.POINTER(KnnTree), vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
-    L.rt_dp_trace_closest.argtypes = [vp, C.POINTER(Bvh4), C.POINTER(vp * 3), C.POINTER(vp * 3), C.c_uint32, C.c_float, vp, vp,
+    L.rt_dp_trace_closest.argtypes = [vp, C.POINTER(Bvh4), C.POINTER(vp * 3), C.POINTER(vp * 3), C.c_uint32, C.c_float, C.c_uint32, vp, vp,
                                       C.POINTER(C.c_uint64 * 4)]
     L.rt_dp_last_error.restype = C.c_char_p
     L.rt_dp_version.restype = C.c_char_p
@@ -365,7 +368,7 @@ class Context:
         _check(self._L.rt_dp_knn_tree_euclid16(self._h, C.byref(ct), queries.data_ptr(), home_leaf.data_ptr(), m, splits, bound.data_ptr(),
                                                out_dist.data_ptr(), out_idx.data_ptr(), C.c_void_p(stream) if stream else None))
 
-    def trace_closest(self, nodes, tris, origin, direction, extent, out_t, out_tri):
+    def trace_closest(self, nodes, tris, origin, direction, extent, out_t, out_tri, wavefront=False):
         """Closest hit of every ray in a 4-wide hierarchy (torch CUDA tensors).  nodes [m,32] float32, tris [n,12] float32,
         origin / direction: lists of three float32 tensors [r]; out_t float32 [r], out_tri int32 [r] (bit image of uint32).
         Returns {levels, box_ops, tri_ops, widest_queue}.  Synchronous."""
@@ -378,7 +381,7 @@ class Context:
         o = (C.c_void_p * 3)(*[t.data_ptr() for t in origin])
         d = (C.c_void_p * 3)(*[t.data_ptr() for t in direction])
         stats = (C.c_uint64 * 4)()
-        _check(self._L.rt_dp_trace_closest(self._h, C.byref(bvh), C.byref(o), C.byref(d), r, float(extent), out_t.data_ptr(), out_tri.data_ptr(),
+        _check(self._L.rt_dp_trace_closest(self._h, C.byref(bvh), C.byref(o), C.byref(d), r, float(extent), TRACE_WAVEFRONT if wavefront else 0, out_t.data_ptr(), out_tri.data_ptr(),
                                            C.byref(stats)))
         return {"levels": stats[0], "box_ops": stats[1], "tri_ops": stats[2], "widest_queue": stats[3]}
 

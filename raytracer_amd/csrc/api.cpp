@@ -581,9 +581,10 @@ int regrow(char *&buf, size_t &have, size_t want, const char *what) {
 }  // namespace
 
 int rt_dp_trace_closest(rt_dp_ctx *ctx, const rt_dp_bvh4 *bvh, const float *const origin[3], const float *const dir[3],
-                        uint32_t n_rays, float extent, float *out_t, uint32_t *out_tri, uint64_t stats[4]) {
+                        uint32_t n_rays, float extent, uint32_t flags, float *out_t, uint32_t *out_tri, uint64_t stats[4]) {
     if (!ctx || !bvh || !origin || !dir) return fail(RT_DP_ENULL, "rt_dp_trace_closest: NULL argument");
     if (bvh->struct_size != sizeof(rt_dp_bvh4)) return fail(RT_DP_EINVAL, "rt_dp_bvh4.struct_size does not match this library");
+    if (flags & ~RT_DP_TRACE_WAVEFRONT) return fail(RT_DP_EINVAL, "rt_dp_trace_closest: unknown flag bits 0x%x", flags & ~RT_DP_TRACE_WAVEFRONT);
     if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
     if (n_rays == 0) return RT_DP_OK;
     if (!out_t || !out_tri || !bvh->nodes || (bvh->n_tris && !bvh->tris)) return fail(RT_DP_ENULL, "rt_dp_trace_closest: NULL array");
@@ -602,20 +603,14 @@ int rt_dp_trace_closest(rt_dp_ctx *ctx, const rt_dp_bvh4 *bvh, const float *cons
     hipStream_t s = ctx->stream;
     HIP_TRY(hipDeviceSynchronize());  // the caller's arrays may still be in flight on other streams
 
-    const size_t ray_bytes = (size_t)n_rays * 64, best_bytes = (size_t)n_rays * 8;
+    const bool wavefront = (flags & RT_DP_TRACE_WAVEFRONT) != 0;
+    const size_t ray_bytes = wavefront ? (size_t)n_rays * 64 : 0, best_bytes = wavefront ? (size_t)n_rays * 8 : 0;
     HIP_TRY(hipStreamSynchronize(s));
     int rc = regrow(ctx->d_trace, ctx->trace_bytes, ray_bytes + best_bytes + 256, "ray records");
     if (rc != RT_DP_OK) return rc;
     float *rays = reinterpret_cast<float *>(ctx->d_trace);
     unsigned long long *best = reinterpret_cast<unsigned long long *>(ctx->d_trace + ray_bytes);
     uint32_t *counters = reinterpret_cast<uint32_t *>(ctx->d_trace + ray_bytes + best_bytes);
-    const size_t first_items = (size_t)n_rays + (size_t)n_rays / 2 + 1024;
-    for (int q = 0; q < 3; ++q) {
-        size_t bytes = ctx->queue_items[q] * 8;
-        rc = regrow(ctx->d_queue[q], bytes, first_items * 8, "work queue");
-        ctx->queue_items[q] = bytes / 8;
-        if (rc != RT_DP_OK) return rc;
-    }
     {
         uint32_t bad = 0;
         HIP_TRY(hipMemsetAsync(counters, 0, 16, s));
@@ -624,6 +619,25 @@ int rt_dp_trace_closest(rt_dp_ctx *ctx, const rt_dp_bvh4 *bvh, const float *cons
         HIP_TRY(hipStreamSynchronize(s));
         if (bad)
             return fail(RT_DP_EINVAL, "node %u holds a child reference outside the hierarchy (inner children must have a larger index than their parent)", bad - 1);
+    }
+    if (!wavefront) {
+        unsigned long long *totals = reinterpret_cast<unsigned long long *>(counters);  // [0] box ops, [1] triangle ops, then the overflow flag
+        uint32_t *overflow = counters + 4;
+        HIP_TRY(hipMemsetAsync(counters, 0, 32, s));
+        HIP_TRY(trace_dfs(origin, dir, n_rays, extent, bvh->nodes, bvh->tris, out_t, out_tri, totals, overflow, s));
+        unsigned long long host[3];
+        HIP_TRY(hipMemcpyAsync(host, counters, 24, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (host[2] & 0xFFFFFFFFull) return fail(RT_DP_EINVAL, "a ray had more than 64 pending entries: the hierarchy is too deep for the depth-first walk");
+        if (stats) { stats[1] = host[0]; stats[2] = host[1]; }
+        return RT_DP_OK;
+    }
+    const size_t first_items = (size_t)n_rays + (size_t)n_rays / 2 + 1024;
+    for (int q = 0; q < 3; ++q) {
+        size_t bytes = ctx->queue_items[q] * 8;
+        rc = regrow(ctx->d_queue[q], bytes, first_items * 8, "work queue");
+        ctx->queue_items[q] = bytes / 8;
+        if (rc != RT_DP_OK) return rc;
     }
     int cur = 0, nxt = 1;
     const int lf = 2;

@@ -178,6 +178,111 @@ __global__ __launch_bounds__(256) void k_trace_tri(const uint2 *__restrict__ lea
     if (mine != kBestNone) atomicMin(best + item.x, mine);
 }
 
+// ---- depth-first variant: one lane walks one ray with a private stack ------------------
+// The order the Quadbox op delivers (closest child first, hits first) is what a stack
+// traversal wants: the hit children are pushed farthest first, so the nearest is popped
+// next, and once a triangle is found every entry whose entry distance is not below the best
+// t is dropped when popped.  Per ray, in this order:
+//   pop (ref, tmin); limit = min(extent, best t); skip unless tmin < limit;
+//   leaf: triangle op on each triangle in turn, a hit (t = t_num / t_denom, IEEE division, -0
+//         read as +0, NaN ignored) replaces best when (t, triangle) is smaller;
+//   node: Quadbox op with extent = limit; push the hit children in reverse sorted order.
+// A ray's walk is sequential, so the result is deterministic by construction.
+constexpr int kStackDepth = 64;
+
+__global__ __launch_bounds__(256) void k_trace_dfs(const float *ox, const float *oy, const float *oz, const float *dx, const float *dy,
+                                                   const float *dz, uint32_t n, float extent, const float *__restrict__ nodes,
+                                                   const float *__restrict__ tris, float *__restrict__ out_t, uint32_t *__restrict__ out_tri,
+                                                   unsigned long long *__restrict__ totals, uint32_t *__restrict__ overflow) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool live = i < n;
+    const uint32_t ii = live ? i : n - 1;
+    float r[kBoxFields];
+    r[0] = ox[ii]; r[1] = oy[ii]; r[2] = oz[ii];
+    const float d[3] = {dx[ii], dy[ii], dz[ii]};
+    float inv[3], shear[3];
+    uint32_t kw;
+    ray_derive(d, inv, kw, shear);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { r[3 + c] = d[c]; r[6 + c] = inv[c]; }
+
+    uint2 stack[kStackDepth];  // (reference, bits of the entry distance)
+    int sp = 0;
+    if (live) stack[sp++] = uint2{0u, 0u};  // the root, entry distance +0
+    unsigned long long best = kBestNone;
+    uint32_t n_box = 0, n_tri = 0;
+    bool spilled = false;
+
+    while (__any(sp > 0)) {
+        uint32_t ref = kRefNone;
+        float limit = 0.0f;
+        if (sp > 0) {
+            const uint2 e = stack[--sp];
+            const float found = __uint_as_float((uint32_t)(best >> 32));
+            limit = (found < extent) ? found : extent;
+            if (__uint_as_float(e.y) < limit) ref = e.x;
+        }
+        if (ref != kRefNone && !(ref & kRefLeaf)) {
+            const f4v *nn = reinterpret_cast<const f4v *>(nodes + (size_t)ref * kNodeWords);
+            r[9] = limit;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const f4v v = nn[q];
+                r[10 + 4 * q] = v.x; r[11 + 4 * q] = v.y; r[12 + 4 * q] = v.z; r[13 + 4 * q] = v.w;
+            }
+            const u4v child = reinterpret_cast<const u4v *>(nn)[6];
+            float t[4];
+            uint32_t flags;
+            box_one(r, t, flags);
+            ++n_box;
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {  // farthest first: the nearest child ends up on top
+                const uint32_t slot = (flags >> (4 + 2 * k)) & 3u;
+                const uint32_t c = (slot == 0u) ? child.x : (slot == 1u) ? child.y : (slot == 2u) ? child.z : child.w;
+                if (((flags >> k) & 1u) && c != kRefNone) {
+                    if (sp < kStackDepth) stack[sp++] = uint2{c, __float_as_uint(t[k])};
+                    else spilled = true;
+                }
+            }
+        } else if (ref != kRefNone) {
+            const uint32_t first = (ref & ~kRefLeaf) >> 3, cnt = (ref & 7u) + 1u;
+            float q[kTriFields];
+            q[0] = r[0]; q[1] = r[1]; q[2] = r[2]; q[3] = shear[0]; q[4] = shear[1]; q[5] = shear[2];
+            for (uint32_t j = 0; j < cnt; ++j) {
+                const f4v *tt = reinterpret_cast<const f4v *>(tris + (size_t)(first + j) * kTriWords);
+                const f4v a = tt[0], b = tt[1], c = tt[2];
+                q[6] = a.x; q[7] = a.y; q[8] = a.z; q[9] = a.w; q[10] = b.x; q[11] = b.y; q[12] = b.z; q[13] = b.w; q[14] = c.x;
+                float num, den;
+                uint32_t hit;
+                tri_one(q, kw, num, den, hit);
+                if (hit) {
+                    float t = num / den;
+                    if (t == t) {
+                        if (t == 0.0f) t = 0.0f;
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (first + j);
+                        best = (key < best) ? key : best;
+                    }
+                }
+            }
+            n_tri += cnt;
+        }
+    }
+    if (live) {
+        out_t[i] = __uint_as_float((uint32_t)(best >> 32));
+        out_tri[i] = (uint32_t)best;
+        if (spilled) atomicOr(overflow, 1u);
+    }
+    // statistics: one atomic pair per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        n_box += __shfl_down(n_box, off);
+        n_tri += __shfl_down(n_tri, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (n_box) atomicAdd(&totals[0], (unsigned long long)n_box);
+        if (n_tri) atomicAdd(&totals[1], (unsigned long long)n_tri);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_trace_finish(const unsigned long long *__restrict__ best, uint32_t n, float *__restrict__ out_t,
                                                       uint32_t *__restrict__ out_tri) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -210,6 +315,13 @@ hipError_t trace_tri(const void *leaf, uint32_t count, const float *rays, const 
                      hipStream_t s) {
     hipLaunchKernelGGL(k_trace_tri, dim3((count + 255) / 256), dim3(256), 0, s, static_cast<const uint2 *>(leaf), count, rays, tris, best,
                        counters);
+    return hipGetLastError();
+}
+
+hipError_t trace_dfs(const float *const origin[3], const float *const dir[3], uint32_t n, float extent, const float *nodes, const float *tris,
+                     float *out_t, uint32_t *out_tri, unsigned long long *totals, uint32_t *overflow, hipStream_t s) {
+    hipLaunchKernelGGL(k_trace_dfs, dim3((n + 255) / 256), dim3(256), 0, s, origin[0], origin[1], origin[2], dir[0], dir[1], dir[2], n, extent,
+                       nodes, tris, out_t, out_tri, totals, overflow);
     return hipGetLastError();
 }
 

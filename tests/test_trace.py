@@ -38,30 +38,32 @@ def test_bvh4_is_a_partition_with_enclosing_boxes():
     assert one.shape[0] == 1 and sum(int(x & 7) + 1 for x in r if x != bvh.NONE) == 3  # a root of leaves
 
 
-def run_gpu(ctx, torch, nodes, tris12, org, dirs, extent):
+def run_gpu(ctx, torch, nodes, tris12, org, dirs, extent, wavefront=False):
     dev = "cuda"
     N, T = torch.from_numpy(nodes).to(dev), torch.from_numpy(tris12).to(dev)
     o = [torch.from_numpy(np.ascontiguousarray(org[:, a])).to(dev) for a in range(3)]
     d = [torch.from_numpy(np.ascontiguousarray(dirs[:, a])).to(dev) for a in range(3)]
     t = torch.empty(org.shape[0], dtype=torch.float32, device=dev)
     i = torch.empty(org.shape[0], dtype=torch.int32, device=dev)
-    stats = ctx.trace_closest(N, T, o, d, extent, t, i)
+    stats = ctx.trace_closest(N, T, o, d, extent, t, i, wavefront=wavefront)
     return t.cpu().numpy(), i.cpu().numpy().view(u32), stats
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_tris,n_rays,leaf,jitter,extent", [(1, 50, 4, 0.0, 4000.0), (37, 500, 1, 5.0, 4000.0), (5000, 20000, 4, 0.0, 4000.0),
                                                               (5000, 20000, 8, 30.0, 4000.0), (20000, 50000, 2, 10.0, 900.0)])
-def test_trace_matches_the_oracle_model(ctx, oracle, torch_cuda, n_tris, n_rays, leaf, jitter, extent):
-    from trace_model import trace_closest
+@pytest.mark.parametrize("wavefront", [False, True])
+def test_trace_matches_the_oracle_model(ctx, oracle, torch_cuda, n_tris, n_rays, leaf, jitter, extent, wavefront):
+    from trace_model import trace_closest, trace_closest_dfs
     tris = bvh.random_scene(n_tris, seed=n_tris)
     nodes, tris12, order = bvh.build_bvh4(tris, leaf_size=leaf)
     org, dirs = bvh.rays_towards(tris, n_rays, seed=n_rays, jitter=jitter)
     dirs[3] = 0.0                    # a degenerate ray: inv = Inf, 0 * Inf = NaN in the slab test
     org[4] = np.nan
     dirs[5, 1] = 0.0                 # axis-parallel component
-    want_t, want_i, want_stats = trace_closest(oracle, nodes, tris12, org, dirs, extent)
-    got_t, got_i, stats = run_gpu(ctx, torch_cuda, nodes, tris12, org, dirs, extent)
+    model = trace_closest if wavefront else trace_closest_dfs
+    want_t, want_i, want_stats = model(oracle, nodes, tris12, org, dirs, extent)
+    got_t, got_i, stats = run_gpu(ctx, torch_cuda, nodes, tris12, org, dirs, extent, wavefront)
     assert (got_i == want_i).all() and (got_t.view(u32) == want_t.view(u32)).all()
     assert stats == want_stats
     hit = got_i != 0xFFFFFFFF
@@ -70,13 +72,14 @@ def test_trace_matches_the_oracle_model(ctx, oracle, torch_cuda, n_tris, n_rays,
 
 
 @pytest.mark.gpu
-def test_trace_agrees_with_testing_every_triangle(ctx, oracle, torch_cuda):
+@pytest.mark.parametrize("wavefront", [False, True])
+def test_trace_agrees_with_testing_every_triangle(ctx, oracle, torch_cuda, wavefront):
     """Sanity beyond parity: the hierarchy only skips triangles, it never invents hits, and with generous
     boxes it finds what an exhaustive triangle test finds."""
     tris = bvh.random_scene(600, seed=3)
     nodes, tris12, order = bvh.build_bvh4(tris, leaf_size=4)
     org, dirs = bvh.rays_towards(tris, 400, seed=4, jitter=2.0)
-    got_t, got_i, _ = run_gpu(ctx, torch_cuda, nodes, tris12, org, dirs, 4000.0)
+    got_t, got_i, _ = run_gpu(ctx, torch_cuda, nodes, tris12, org, dirs, 4000.0, wavefront)
     from raytracer_amd import gen
     inv, kx, ky, kz, shear = gen.ray_derived(dirs)
     kw = gen.pack_k(kx, ky, kz)

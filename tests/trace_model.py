@@ -55,3 +55,61 @@ def trace_closest(O, nodes, tris12, org, dirs, extent):
         ray, node = np.concatenate(nxt_ray), np.concatenate(nxt_node)
         stats["widest_queue"] = max(stats["widest_queue"], int(ray.size), int(lray.size))
     return (best >> u64(32)).astype(u32).view(f32), (best & u64(0xFFFFFFFF)).astype(u32), stats
+
+
+def trace_closest_dfs(O, nodes, tris12, org, dirs, extent, depth=64):
+    """The depth-first walk, all rays in lock step: every live ray pops one entry per round; the rays that popped
+    a node run their Quadbox ops as one oracle batch, the rays that popped a leaf their triangle ops."""
+    n = org.shape[0]
+    inv, kx, ky, kz, shear = gen.ray_derived(dirs)
+    kw = gen.pack_k(kx, ky, kz)
+    refs = nodes[:, 24:28].copy().view(u32)
+    best = np.full(n, BEST_NONE, u64)
+    st_ref = np.zeros((n, depth), u32)
+    st_t = np.zeros((n, depth), f32)
+    sp = np.ones(n, np.int64)           # the root with entry distance +0
+    box_ops = tri_ops = 0
+    while True:
+        act = np.nonzero(sp > 0)[0]
+        if act.size == 0:
+            break
+        sp[act] -= 1
+        ref, tmin = st_ref[act, sp[act]], st_t[act, sp[act]]
+        found = (best[act] >> u64(32)).astype(u32).view(f32)
+        limit = np.where(found < f32(extent), found, f32(extent)).astype(f32)
+        keep = tmin < limit
+        act, ref, limit = act[keep], ref[keep], limit[keep]
+        is_leaf = (ref & u32(bvh.LEAF)) != 0
+        ray, node, lim = act[~is_leaf], ref[~is_leaf].astype(np.int64), limit[~is_leaf]
+        if ray.size:
+            box_ops += int(ray.size)
+            fields = [org[ray, a] for a in range(3)] + [dirs[ray, a] for a in range(3)] + [inv[ray, a] for a in range(3)] + [lim]
+            fields += [nodes[node, w] for w in range(24)]
+            t, flags = O.box_soa(fields)
+            for k in (3, 2, 1, 0):
+                hit = ((flags >> u32(k)) & u32(1)).astype(bool)
+                slot = ((flags >> u32(4 + 2 * k)) & u32(3)).astype(np.int64)
+                c = refs[node, slot]
+                ok = hit & (c != u32(bvh.NONE))
+                rr = ray[ok]
+                assert (sp[rr] < depth).all()
+                st_ref[rr, sp[rr]] = c[ok]
+                st_t[rr, sp[rr]] = t[k][ok]
+                sp[rr] += 1
+        lray, lref = act[is_leaf], ref[is_leaf]
+        if lray.size:
+            first = ((lref & u32(0x7FFFFFFF)) >> u32(3)).astype(np.int64)
+            cnt = (lref & u32(7)).astype(np.int64) + 1
+            tray = np.repeat(lray, cnt)
+            tid = np.repeat(first, cnt) + (np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+            tri_ops += int(tid.size)
+            tf = [org[tray, a] for a in range(3)] + [shear[tray, a] for a in range(3)] + [tris12[tid, w] for w in range(9)]
+            num, den, hit = O.tri_soa(tf, kw[tray])
+            with np.errstate(all="ignore"):
+                t = (num / den).astype(f32)
+            ok = (hit != 0) & ~np.isnan(t)
+            t = np.where(t == 0, f32(0), t).astype(f32)
+            key = (t.view(u32).astype(u64) << u64(32)) | tid.astype(u64)
+            np.minimum.at(best, tray[ok], key[ok])   # within a leaf the smallest key wins, as in the sequential walk
+    stats = {"levels": 0, "box_ops": box_ops, "tri_ops": tri_ops, "widest_queue": 0}
+    return (best >> u64(32)).astype(u32).view(f32), (best & u64(0xFFFFFFFF)).astype(u32), stats
