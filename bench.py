@@ -402,8 +402,15 @@ def run_knn(a, world, rank, local, dev):
 def main():
     a = parse()
     world, rank, local = dist_util.env_world()
-    torch.cuda.set_device(local)
-    dist_util.init("nccl")  # RCCL; a no-op for a single process
+    if os.environ.get("RT_DP_REHEARSE_ONE_GPU") == "1":
+        # rehearsal of the N > 1 control path on a one-GPU box: every rank uses GPU 0 and the
+        # control collectives go over gloo (RCCL refuses two ranks on one device); timings are meaningless
+        local = 0
+        torch.cuda.set_device(0)
+        dist_util.init("gloo")
+    else:
+        torch.cuda.set_device(local)
+        dist_util.init("nccl")  # RCCL; a no-op for a single process
     dist = torch.distributed if world > 1 else None
     dev = torch.device("cuda", local)
     n = 1 << a.log2_ops
