@@ -50,6 +50,7 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=10.0)
     p.add_argument("--knn-log2-points", type=int, default=20)
     p.add_argument("--knn-log2-queries", type=int, default=16)
+    p.add_argument("--stream-mode", type=int, default=0, help="record streams: 0 automatic, 1 partition by opcode first, 2 fused single pass")
     p.add_argument("--trace-wavefront", type=int, default=0, help="1: breadth-first walk with queue compaction; 0: depth-first walk")
     p.add_argument("--trace-log2-tris", type=int, default=18)
     p.add_argument("--trace-log2-rays", type=int, default=22)
@@ -278,6 +279,7 @@ def run_stream(a, world, rank, local, dev):
     rec[:, 83] = torch.randint(0, 2, (n,), generator=g, device=dev, dtype=torch.int32)
     out = torch.empty(n, 21, dtype=torch.int32, device=dev)
     ctx = capi.Context(device=local)
+    ctx.set_option("stream_mode", a.stream_mode)
     torch.cuda.synchronize()
     for _ in range(a.warmup):
         ctx.eval_bundles_device(rec, out)
@@ -296,7 +298,7 @@ def run_stream(a, world, rank, local, dev):
                           "config": {"workload": "stream: 2^%d EnhancedInputBundle records per GPU resident in HBM, opcode ~ U{0..3}" % a.log2_ops},
                           "roofline": {"bound": "hbm", "achieved": round(n * 420 / per / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(n * 420 / per / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                                       "note": "420 B per record = 336 B record in + 84 B record out; the partition moves every live operand twice more"}}), flush=True)
+                                       "note": "420 B per record = 336 B record in + 84 B record out; mode %d (1: partition first, moves every live operand twice more; 0/2: fused single pass)" % a.stream_mode}}), flush=True)
     ctx.close()
     dist_util.shutdown()
 

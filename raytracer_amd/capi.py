@@ -321,6 +321,9 @@ class Context:
         _check(self._L.rt_dp_set_option(self._h, b"variant", variant))
         _check(self._L.rt_dp_set_option(self._h, b"vec_passes", vec_passes))
 
+    def set_option(self, key, value):
+        _check(self._L.rt_dp_set_option(self._h, key.encode(), int(value)))
+
     def eval_bundles_device(self, d_in, d_out):
         """Record stream resident in HBM: d_in int32 CUDA tensor [n, 84], d_out int32 CUDA tensor [n, 21]."""
         assert d_in.is_cuda and d_out.is_cuda and d_in.is_contiguous() and d_out.is_contiguous()

@@ -60,6 +60,7 @@ struct rt_dp_ctx {
     char *d_queue[3] = {nullptr, nullptr, nullptr};
     size_t queue_items[3] = {0, 0, 0};
     Tuning tuning{0, 0, 0, 0, 0};
+    int stream_mode = 0;  // record streams in HBM: 0 automatic, 1 partition by opcode first, 2 fused single pass
 };
 
 namespace {
@@ -431,6 +432,28 @@ int rt_dp_eval_bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt
         have = want;
         return RT_DP_OK;
     };
+    const bool aligned16 = ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15u) == 0;
+    if (ctx->stream_mode == 2 && !aligned16) return fail(RT_DP_EALIGN, "the fused record-stream path needs 16-byte aligned record arrays");
+    if (ctx->stream_mode == 2 || (ctx->stream_mode == 0 && aligned16)) {
+        // one pass over the records: evaluate in place, then add up the distance beats in stream order
+        int rc = grow(ctx->d_stream, ctx->stream_bytes, stream_fused_workspace(n));
+        if (rc != RT_DP_OK) return rc;
+        StreamSideView view;
+        uint32_t *out_words = reinterpret_cast<uint32_t *>(d_out);
+        HIP_TRY(stream_fused_eval(reinterpret_cast<const uint32_t *>(d_in), n, ctx->extended ? 1 : 0, out_words, ctx->d_stream, &view, s));
+        if (ctx->extended) {
+            float *cur = ctx->d_state + 4 * ctx->cur, *nxt = ctx->d_state + 4 * (ctx->cur ^ 1);
+            // registers of an opcode without beats in this stream are carried over unchanged
+            HIP_TRY(hipMemcpyAsync(nxt, cur, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
+            HIP_TRY(stream_fused_fold(view, n, cur, nxt, out_words, s));
+        }
+        uint32_t bad = 0;
+        HIP_TRY(hipMemcpyAsync(&bad, view.flags, sizeof bad, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (bad) return fail(RT_DP_EOPCODE, "the record stream holds an opcode > 3; the RTL's opcode field is 2 bits wide");
+        if (ctx->extended) ctx->cur ^= 1;
+        return RT_DP_OK;
+    }
     const uint64_t nblk = (n + 255) / 256;
     const size_t off_slot = 0, off_cnt = align_up(n * 4), off_tot = off_cnt + align_up(nblk * 16);
     int rc = grow(ctx->d_stream, ctx->stream_bytes, off_tot + 256);
@@ -689,6 +712,9 @@ int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value) {
     if (!strcmp(key, "variant")) {
         if (!(value == 0 || value == 10)) return fail(RT_DP_EINVAL, "variant must be 0 or 10 (diagnostic)");
         ctx->tuning.variant = value;
+    } else if (!strcmp(key, "stream_mode")) {
+        if (value < 0 || value > 2) return fail(RT_DP_EINVAL, "stream_mode must be 0 (automatic), 1 (partition) or 2 (fused)");
+        ctx->stream_mode = value;
     } else if (!strcmp(key, "vec_passes")) {
         if (value != 0 && value != 2 && value != 4 && value != 8) return fail(RT_DP_EINVAL, "vec_passes must be 0, 2, 4 or 8");
         ctx->tuning.vec_passes = value;

@@ -69,6 +69,17 @@ hipError_t launch_ray_prepare(const RayPrepArgs &args, uint64_t n, hipStream_t s
 // out_d / out_i: [splits][n_qry][16], ascending by (distance, index); unused slots hold (+Inf, 0xFFFFFFFF).
 hipError_t launch_knn_euclid16(const float *pts, uint32_t n_pts, const float *qry, uint32_t n_qry, uint32_t idx_base,
                                uint32_t splits, float *out_d, uint32_t *out_i, hipStream_t stream);
+// fused record-stream path (stream_fused.hip)
+struct StreamSideView {
+    const uint32_t *tag;
+    const float *sum0, *sum1;
+    const uint32_t *rbits[2];
+    const uint32_t *flags;  // [0] opcode > 3 seen, [1] opcode 2 present, [2] opcode 3 present
+};
+size_t stream_fused_workspace(uint64_t n);
+hipError_t stream_fused_eval(const uint32_t *in, uint64_t n, int extended, uint32_t *out, char *workspace, StreamSideView *view, hipStream_t s);
+hipError_t stream_fused_fold(const StreamSideView &v, uint64_t n, const float *state_in, float *state_out, uint32_t *out, hipStream_t s);
+
 // traversal driver (trace.hip); queues hold (ray, node or leaf reference) pairs of 8 bytes
 hipError_t trace_validate(const float *nodes, uint32_t n_nodes, uint32_t n_tris, uint32_t *bad, hipStream_t s);
 hipError_t trace_init(const float *const origin[3], const float *const dir[3], uint32_t n, float extent, float *rays,

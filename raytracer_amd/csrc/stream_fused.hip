@@ -1,0 +1,380 @@
+// Record streams in HBM, fused form: EnhancedInputBundle images in arrival order are read
+// ONCE, evaluated in place and written back as EnhancedOutputBundle images, without moving
+// the operands into per-opcode arrays first (stream.hip does that; this file is the faster
+// way to the same bits).
+//
+//   k_stream_eval   one wave per 64 consecutive records.  The wave copies its 21 KiB of
+//                   records into LDS with coalesced 16-byte loads (a lane-per-record read
+//                   would touch 64 cache lines per instruction), then each lane evaluates
+//                   its own record: Quadbox and triangle ops completely; for a distance beat
+//                   the tree sum(s) of the beat, which do not depend on the accumulator.
+//                   The 21-word output records go back through LDS to coalesced stores.
+//                   Side arrays receive, per record, tag = opcode | reset << 2 and the
+//                   beat's tree sums, plus one bit per 64 records and distance opcode
+//                   saying "a reset of this opcode occurs here".
+//   k_stream_fold   per distance opcode: the accumulator is a strictly sequential float sum
+//                   over the beats of one vector pair IN STREAM ORDER (reference
+//                   src/main/scala/raytracer_datapath/UnifiedDatapath.scala:1133-1154,
+//                   :1028-1064), so a workgroup owns whole pairs: its range of records runs
+//                   from the first pair boundary at or after blockIdx * tile to the first one
+//                   at or after (blockIdx + 1) * tile (a boundary follows a record of this
+//                   opcode that carries the reset bit; found through the bit summaries, so
+//                   long stretches without one cost 128 Ki records per step).  Inside a
+//                   sub-tile the opcode's beats are compacted into LDS in stream order, one
+//                   lane per pair adds them up, and the results are patched into the output
+//                   records.
+// Output fields of foreign opcodes are zero and the two *_reset_accum fields echo the input
+// bit for every opcode (:1205, :1254, :1267-1268).
+#include "ops.hpp"
+
+#pragma clang fp contract(off)
+
+namespace rtdp {
+
+constexpr int kRecIn = 84;    // words per rt_dp_input_bundle
+constexpr int kRecOut = 21;   // words per rt_dp_output_bundle
+constexpr int kWaveRecs = 64;
+
+struct StreamSide {
+    uint32_t *tag;        // [n]   opcode | reset << 2
+    float *sum0, *sum1;   // [n]   tree sums of a distance beat (Euclidean: sum0; angular: dot, norm)
+    uint32_t *rbits[2];   // [ceil(n / 2048)] bit b of word w: records [(32 w + b) * 64, +64) hold a reset of opcode 2 / 3
+    uint32_t *flags;      // [0] an opcode > 3 was seen, [1] opcode 2 present, [2] opcode 3 present
+};
+
+__device__ __forceinline__ float tree16(const float (&s)[16]) {  // (i, i+8), (i, i+4), (i, i+2), (0, 1)
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = s[i] + s[i + 8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = t[i] + t[i + 4];
+    return (t[0] + t[2]) + (t[1] + t[3]);
+}
+
+__device__ __forceinline__ float tree8(const float (&s)[8]) {  // (i, i+4), (i, i+2), (0, 1)
+    float t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = s[i] + s[i + 4];
+    return (t[0] + t[2]) + (t[1] + t[3]);
+}
+
+__global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__ in, uint64_t n, int extended, uint32_t *__restrict__ out,
+                                                    StreamSide side) {
+    __shared__ __align__(16) uint32_t s_rec[kWaveRecs * kRecIn];  // 21 KiB; re-used for the output records
+    const int lane = threadIdx.x;
+    const uint64_t r0 = (uint64_t)blockIdx.x * kWaveRecs;
+    const uint32_t live = (n - r0 < (uint64_t)kWaveRecs) ? (uint32_t)(n - r0) : (uint32_t)kWaveRecs;
+
+    // coalesced copy of the wave's records into LDS (record r, word w -> s_rec[84 r + w])
+    {
+        const u4v *src = reinterpret_cast<const u4v *>(in + r0 * kRecIn);
+        const uint32_t chunks = live * (kRecIn / 4);
+        u4v v[kRecIn / 4];
+#pragma unroll
+        for (int j = 0; j < kRecIn / 4; ++j) {
+            const uint32_t g = (uint32_t)j * 64u + lane;
+            v[j] = (g < chunks) ? __builtin_nontemporal_load(src + g) : u4v{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int j = 0; j < kRecIn / 4; ++j) reinterpret_cast<u4v *>(s_rec)[j * 64 + lane] = v[j];
+    }
+    __syncthreads();
+
+    // 16-byte LDS reads of the own record: 21 is odd, so the lanes of a read spread over all banks
+    const u4v *rc = reinterpret_cast<const u4v *>(s_rec + lane * kRecIn);
+    const bool have = (uint32_t)lane < live;
+    const u4v c0 = rc[0];
+    const uint32_t op = have ? c0.x : 0xFFFFFFFFu;
+    const uint32_t reset = have ? (rc[20].w & 1u) : 0u;
+    uint32_t w[kRecOut];
+#pragma unroll
+    for (int k = 0; k < kRecOut; ++k) w[k] = 0u;
+    float sum0 = 0.0f, sum1 = 0.0f;
+    if (have) {
+        w[0] = op;
+        if (extended) { w[17] = reset; w[20] = reset; }
+    }
+    if (op == 1u) {  // Quadbox: words 1..10 (ray) and 17..40 (four AABBs)
+        uint32_t W[44];
+        W[1] = c0.y; W[2] = c0.z; W[3] = c0.w;
+#pragma unroll
+        for (int c = 1; c <= 10; ++c) {
+            if (c == 3) continue;
+            const u4v v = rc[c];
+            W[4 * c] = v.x; W[4 * c + 1] = v.y; W[4 * c + 2] = v.z; W[4 * c + 3] = v.w;
+        }
+        float r[kBoxFields], t[4];
+#pragma unroll
+        for (int f = 0; f < 10; ++f) r[f] = __uint_as_float(W[1 + f]);
+#pragma unroll
+        for (int f = 0; f < 24; ++f) r[10 + f] = __uint_as_float(W[17 + f]);
+        uint32_t fl;
+        box_one(r, t, fl);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            w[1 + k] = __float_as_uint(t[k]);
+            w[5 + k] = (fl >> k) & 1u;
+            w[9 + k] = (fl >> (4 + 2 * k)) & 3u;
+        }
+    } else if (op == 0u) {  // Triangle: words 1..3 origin, 11..13 k, 14..16 shear, 41..49 vertices
+        const u4v c2 = rc[2], c3 = rc[3], c4 = rc[4], c10 = rc[10], c11 = rc[11], c12 = rc[12];
+        float r[kTriFields];
+        r[0] = __uint_as_float(c0.y); r[1] = __uint_as_float(c0.z); r[2] = __uint_as_float(c0.w);
+        r[3] = __uint_as_float(c3.z); r[4] = __uint_as_float(c3.w); r[5] = __uint_as_float(c4.x);
+        r[6] = __uint_as_float(c10.y); r[7] = __uint_as_float(c10.z); r[8] = __uint_as_float(c10.w);
+        r[9] = __uint_as_float(c11.x); r[10] = __uint_as_float(c11.y); r[11] = __uint_as_float(c11.z); r[12] = __uint_as_float(c11.w);
+        r[13] = __uint_as_float(c12.x); r[14] = __uint_as_float(c12.y);
+        const uint32_t kw = (c2.w & 3u) | ((c3.x & 3u) << 2) | ((c3.y & 3u) << 4);
+        float num, den;
+        uint32_t hit;
+        tri_one(r, kw, num, den, hit);
+        w[13] = __float_as_uint(num);
+        w[14] = __float_as_uint(den);
+        w[15] = hit;
+    } else if (op == 2u) {  // Euclidean beat: a = words 50..65, b = 66..81, mask = word 82
+        uint32_t W[36];  // words 48..83
+#pragma unroll
+        for (int c = 12; c <= 20; ++c) {
+            const u4v v = rc[c];
+            W[4 * (c - 12)] = v.x; W[4 * (c - 12) + 1] = v.y; W[4 * (c - 12) + 2] = v.z; W[4 * (c - 12) + 3] = v.w;
+        }
+        const uint32_t mask = W[34];
+        float s[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool on = (mask >> i) & 1u;
+            const float d = on ? (__uint_as_float(W[2 + i]) - __uint_as_float(W[18 + i])) : 0.0f;  // :221-245
+            s[i] = d * d;                                                                            // :399-419
+        }
+        sum0 = tree16(s);
+    } else if (op == 3u) {  // Angular beat: query = words 50..57, candidate = 66..73
+        const u4v c12 = rc[12], c13 = rc[13], c14 = rc[14], c16 = rc[16], c17 = rc[17], c18 = rc[18], c20 = rc[20];
+        const uint32_t A[8] = {c12.z, c12.w, c13.x, c13.y, c13.z, c13.w, c14.x, c14.y};
+        const uint32_t B[8] = {c16.z, c16.w, c17.x, c17.y, c17.z, c17.w, c18.x, c18.y};
+        const uint32_t mask = c20.z;
+        float s[8], m[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool on = (mask >> i) & 1u;
+            const float q = on ? __uint_as_float(A[i]) : 0.0f;  // :246-268
+            const float c = on ? __uint_as_float(B[i]) : 0.0f;
+            s[i] = q * c;                                        // :420-453
+            m[i] = c * c;
+        }
+        sum0 = tree8(s);
+        sum1 = tree8(m);
+    } else if (have) {
+        atomicOr(&side.flags[0], 1u);  // cannot occur in the RTL's 2-bit field
+    }
+
+    if (have) {
+        side.tag[r0 + lane] = (op & 3u) | (reset << 2);
+        side.sum0[r0 + lane] = sum0;
+        side.sum1[r0 + lane] = sum1;
+    }
+    {
+        const unsigned long long e = __ballot(op == 2u), a = __ballot(op == 3u);
+        const unsigned long long er = __ballot(op == 2u && reset), ar = __ballot(op == 3u && reset);
+        if (lane == 0) {
+            const uint32_t word = blockIdx.x >> 5, bit = 1u << (blockIdx.x & 31u);
+            if (er) atomicOr(&side.rbits[0][word], bit);
+            if (ar) atomicOr(&side.rbits[1][word], bit);
+            // thousands of waves would queue up on these two words: raise a flag only while it still reads 0
+            if (e && !__hip_atomic_load(&side.flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&side.flags[1], 1u);
+            if (a && !__hip_atomic_load(&side.flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&side.flags[2], 1u);
+        }
+    }
+
+    __syncthreads();  // every lane has read its record: the buffer now takes the output records
+#pragma unroll
+    for (int k = 0; k < kRecOut; ++k) s_rec[lane * kRecOut + k] = w[k];  // stride 21 words is odd: conflict-free
+    __syncthreads();
+    uint32_t *dst = out + r0 * kRecOut;
+    if (live == (uint32_t)kWaveRecs) {  // 1344 words = 336 chunks of 16 bytes
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int g = j * 64 + lane;
+            if (g < kWaveRecs * kRecOut / 4) __builtin_nontemporal_store(reinterpret_cast<const u4v *>(s_rec)[g], reinterpret_cast<u4v *>(dst) + g);
+        }
+    } else {
+        for (uint32_t g = lane; g < live * kRecOut; g += 64) dst[g] = s_rec[g];
+    }
+}
+
+// First boundary of opcode X at or after `nominal`: the smallest p >= nominal such that p == 0 or
+// record p - 1 is an X record with the reset bit; n if there is none.  Executed by one full wave.
+__device__ __forceinline__ uint64_t stream_boundary(const uint32_t *tag, const uint32_t *rbits, uint32_t want, uint64_t nominal, uint64_t n,
+                                                    int lane) {
+    if (nominal == 0) return 0;
+    uint64_t i = nominal - 1;  // the next record to examine
+    const uint64_t nblk = (n + 63) >> 6, nwords = (nblk + 31) >> 5;
+    for (;;) {  // every trip advances i by at least one record: terminates
+        if (i >= n) return n;
+        if ((i & 2047u) == 0) {  // on a summary-word boundary: 64 words = 128 Ki records per trip
+            const uint64_t w0 = i >> 11;
+            const uint32_t bits = (w0 + lane < nwords) ? rbits[w0 + lane] : 0u;
+            const unsigned long long m = __ballot(bits != 0u);
+            if (!m) { i += 64ull * 2048ull; continue; }
+            const int wl = __ffsll((long long)m) - 1;
+            const uint32_t first = __shfl(bits, wl);
+            i = ((w0 + wl) * 32 + (__ffs((int)first) - 1)) << 6;  // the first 64-record block holding a reset of X
+        }
+        const uint64_t b0 = i & ~63ull, idx = b0 + lane;
+        const bool p = idx >= i && idx < n && tag[idx] == want;
+        const unsigned long long m = __ballot(p);
+        if (m) return b0 + (uint64_t)(__ffsll((long long)m) - 1) + 1;
+        i = b0 + 64;
+    }
+}
+
+constexpr int kFoldThreads = 256;
+constexpr int kFoldSub = 1024;  // records per sub-tile
+
+template <bool EUC>
+__device__ __forceinline__ void stream_fold(const uint32_t *__restrict__ tag, const float *__restrict__ sum0, const float *__restrict__ sum1,
+                                            const uint32_t *__restrict__ rbits, uint64_t n, uint32_t tile,
+                                            const float *__restrict__ state_in, float *__restrict__ state_out, uint32_t *__restrict__ out) {
+    constexpr uint32_t X = EUC ? 2u : 3u;
+    __shared__ float c_sum0[kFoldSub], c_sum1[EUC ? 1 : kFoldSub], c_out0[kFoldSub], c_out1[EUC ? 1 : kFoldSub];
+    __shared__ uint16_t c_pos[kFoldSub];
+    __shared__ uint8_t c_rs[kFoldSub];
+    __shared__ uint32_t s_cnt[kFoldSub / 64];
+    __shared__ uint64_t s_range[2];
+    __shared__ float s_carry[2][2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave < 2) {
+        const uint64_t r = stream_boundary(tag, rbits, X | 4u, (uint64_t)(blockIdx.x + wave) * tile, n, lane);
+        if (lane == 0) s_range[wave] = r;
+    }
+    if (tid == 0) {  // only the workgroup that starts at record 0 can inherit a running sum
+        s_carry[0][0] = (blockIdx.x == 0) ? state_in[0] : 0.0f;
+        s_carry[0][1] = (!EUC && blockIdx.x == 0) ? state_in[1] : 0.0f;
+    }
+    __syncthreads();
+    const uint64_t lo = s_range[0], hi = s_range[1];
+    if (lo >= hi) return;
+
+    int par = 0;
+    for (uint64_t base = lo; base < hi; base += kFoldSub) {
+        const int cnt = (hi - base < (uint64_t)kFoldSub) ? (int)(hi - base) : kFoldSub;
+        // compaction of the opcode's beats, in stream order: position p = u * 256 + tid
+        uint32_t tg[kFoldSub / kFoldThreads];
+        unsigned long long mk[kFoldSub / kFoldThreads];
+#pragma unroll
+        for (int u = 0; u < kFoldSub / kFoldThreads; ++u) {
+            const int p = u * kFoldThreads + tid;
+            tg[u] = (p < cnt) ? tag[base + p] : 0xFFu;
+            mk[u] = __ballot((tg[u] & 3u) == X && tg[u] != 0xFFu);
+            if (lane == 0) s_cnt[u * 4 + wave] = (uint32_t)__popcll(mk[u]);
+        }
+        __syncthreads();
+        int m = 0;
+#pragma unroll
+        for (int u = 0; u < kFoldSub / kFoldThreads; ++u) {
+            uint32_t before = 0;
+            for (int k = 0; k < u * 4 + wave; ++k) before += s_cnt[k];
+            const int p = u * kFoldThreads + tid;
+            if ((tg[u] & 3u) == X && tg[u] != 0xFFu) {
+                const uint32_t k = before + (uint32_t)__popcll(mk[u] & ((1ull << lane) - 1ull));
+                c_sum0[k] = sum0[base + p];
+                if (!EUC) c_sum1[k] = sum1[base + p];
+                c_rs[k] = (uint8_t)((tg[u] >> 2) & 1u);
+                c_pos[k] = (uint16_t)p;
+            }
+        }
+        for (int k = 0; k < kFoldSub / 64; ++k) m += (int)s_cnt[k];
+        __syncthreads();
+        if (m == 0) continue;  // wave-uniform: no beat of this opcode here, the carry stays where it is
+
+        // one lane per vector pair accumulates its beats in order
+        for (int t0 = tid; t0 < m; t0 += kFoldThreads) {
+            const bool starts = (t0 == 0) || (c_rs[t0 - 1] != 0);
+            if (starts) {
+                float acc0 = (t0 == 0) ? s_carry[par][0] : 0.0f;
+                float acc1 = (t0 == 0) ? s_carry[par][1] : 0.0f;
+                int i = t0;
+                bool rs;
+                do {
+                    const float o0 = acc0 + c_sum0[i];
+                    c_out0[i] = canon_nan(o0);
+                    rs = c_rs[i] != 0;
+                    acc0 = rs ? 0.0f : o0;
+                    if (!EUC) {
+                        const float o1 = acc1 + c_sum1[i];
+                        c_out1[i] = canon_nan(o1);
+                        acc1 = rs ? 0.0f : o1;
+                    }
+                    ++i;
+                } while (i < m && !rs);
+                if (i == m) {  // exactly one lane reaches the end of the compacted beats
+                    s_carry[par ^ 1][0] = acc0;
+                    s_carry[par ^ 1][1] = acc1;
+                }
+            }
+        }
+        __syncthreads();
+        for (int t0 = tid; t0 < m; t0 += kFoldThreads) {
+            uint32_t *rec = out + (base + c_pos[t0]) * kRecOut;
+            if (EUC) {
+                rec[16] = __float_as_uint(c_out0[t0]);
+            } else {
+                rec[18] = __float_as_uint(c_out0[t0]);
+                rec[19] = __float_as_uint(c_out1[t0]);
+            }
+        }
+        par ^= 1;
+        __syncthreads();
+    }
+    if (hi == n && tid == 0) {  // the workgroup that owns the last record hands the registers on
+        state_out[0] = canon_nan(s_carry[par][0]);
+        if (!EUC) state_out[1] = canon_nan(s_carry[par][1]);
+    }
+}
+
+// blockIdx.y = 0: Euclidean, 1: angular, side by side in one launch; an opcode that does not occur in
+// the stream (flags written by k_stream_eval) costs one load per workgroup.  state: {euclid, dot, norm}.
+__global__ __launch_bounds__(256) void k_stream_fold(StreamSideView v, uint64_t n, uint32_t tile, const float *__restrict__ state_in,
+                                                     float *__restrict__ state_out, uint32_t *__restrict__ out) {
+    if (blockIdx.y == 0) {
+        if (v.flags[1]) stream_fold<true>(v.tag, v.sum0, v.sum1, v.rbits[0], n, tile, state_in, state_out, out);
+    } else {
+        if (v.flags[2]) stream_fold<false>(v.tag, v.sum0, v.sum1, v.rbits[1], n, tile, state_in + 1, state_out + 1, out);
+    }
+}
+
+size_t stream_fused_workspace(uint64_t n) {
+    const uint64_t nblk = (n + 63) / 64, nwords = (nblk + 31) / 32;
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    return 3 * up(n * 4) + 2 * up(nwords * 4) + 256;
+}
+
+hipError_t stream_fused_eval(const uint32_t *in, uint64_t n, int extended, uint32_t *out, char *workspace, StreamSideView *view, hipStream_t s) {
+    const uint64_t nblk = (n + 63) / 64, nwords = (nblk + 31) / 32;
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    StreamSide side;
+    size_t o = 0;
+    side.tag = reinterpret_cast<uint32_t *>(workspace + o); o += up(n * 4);
+    side.sum0 = reinterpret_cast<float *>(workspace + o); o += up(n * 4);
+    side.sum1 = reinterpret_cast<float *>(workspace + o); o += up(n * 4);
+    side.rbits[0] = reinterpret_cast<uint32_t *>(workspace + o); o += up(nwords * 4);
+    side.rbits[1] = reinterpret_cast<uint32_t *>(workspace + o); o += up(nwords * 4);
+    side.flags = reinterpret_cast<uint32_t *>(workspace + o);
+    hipError_t e = hipMemsetAsync(side.rbits[0], 0, 2 * up(nwords * 4) + 256, s);  // both bit arrays and the flags
+    if (e != hipSuccess) return e;
+    if (nblk > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_stream_eval, dim3((unsigned)nblk), dim3(64), 0, s, in, n, extended, out, side);
+    view->tag = side.tag; view->sum0 = side.sum0; view->sum1 = side.sum1;
+    view->rbits[0] = side.rbits[0]; view->rbits[1] = side.rbits[1]; view->flags = side.flags;
+    return hipGetLastError();
+}
+
+hipError_t stream_fused_fold(const StreamSideView &v, uint64_t n, const float *state_in, float *state_out, uint32_t *out, hipStream_t s) {
+    const uint32_t tile = kFoldSub;
+    const uint64_t blocks = (n + tile - 1) / tile;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_stream_fold, dim3((unsigned)blocks, 2), dim3(kFoldThreads), 0, s, v, n, tile, state_in, state_out, out);
+    return hipGetLastError();
+}
+
+}  // namespace rtdp

@@ -281,13 +281,16 @@ def _mixed_stream(seed, nb, nt, pe, pa, edge=0.3):
     return stream
 
 
-@pytest.mark.parametrize("sizes", [(1, 0, 0, 0), (0, 0, 1, 0), (3, 2, 1, 1), (300, 300, 40, 40), (20000, 20000, 3000, 3000)])
+@pytest.mark.parametrize("sizes", [(1, 0, 0, 0), (0, 0, 1, 0), (3, 2, 1, 1), (0, 0, 0, 30), (0, 0, 50, 0), (300, 300, 40, 40),
+                                   (20000, 20000, 3000, 3000), (60000, 10, 2, 900)])
 @pytest.mark.parametrize("extended", [True, False])
-def test_device_record_stream_matches_rtl_oracle(oracle, torch_cuda, sizes, extended):
-    """rt_dp_eval_bundles_device: on-device opcode partition + evaluation + re-assembly, against oracle A."""
+@pytest.mark.parametrize("mode", [1, 2])
+def test_device_record_stream_matches_rtl_oracle(oracle, torch_cuda, sizes, extended, mode):
+    """rt_dp_eval_bundles_device (1: partition by opcode first, 2: fused single pass) against oracle A."""
     torch = torch_cuda
     stream = _mixed_stream(60 + sizes[0], *sizes)
     c = capi.Context(support_euclidean=16 if extended else 0)
+    c.set_option("stream_mode", mode)
     d_in = torch.from_numpy(stream.view(np.int32)).cuda()
     d_out = torch.full((stream.shape[0], 21), -1, dtype=torch.int32, device="cuda")
     c.eval_bundles_device(d_in, d_out)
@@ -303,4 +306,35 @@ def test_device_record_stream_matches_rtl_oracle(oracle, torch_cuda, sizes, exte
     with pytest.raises(capi.RtDpError) as e:
         c.eval_bundles_device(torch.from_numpy(bad.view(np.int32)).cuda(), d_out)
     assert e.value.code == capi.EOPCODE
+    c.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_device_record_stream_carries_accumulators(oracle, torch_cuda, mode):
+    """A stream cut at arbitrary records (inside vector pairs) and fed in pieces equals the stream fed whole; a stream
+    of distance beats without any reset is one long pair."""
+    torch = torch_cuda
+    stream = _mixed_stream(7, 5000, 5000, 700, 700)
+    want, state = oracle.eval_bundles("B", stream.view(oracle.IN_BUNDLE).reshape(-1), extended=True)
+    c = capi.Context()
+    c.set_option("stream_mode", mode)
+    got = []
+    cuts = [0, 1, 64, 1000, 1027, 4096, 9999, stream.shape[0]]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        d_in = torch.from_numpy(np.ascontiguousarray(stream[a:b]).view(np.int32)).cuda()
+        d_out = torch.empty((b - a, 21), dtype=torch.int32, device="cuda")
+        c.eval_bundles_device(d_in, d_out)
+        got.append(d_out.cpu().numpy().view(u32))
+    assert_bits_equal(np.concatenate(got), want.view(u32).reshape(-1, 21), "pieces")
+    assert tuple(int(x) for x in c.get_accum().view(u32)) == state
+    c.reset()
+    endless = stream[stream[:, 0] >= 2].copy()
+    endless[:, 83] = 0
+    endless = np.ascontiguousarray(np.concatenate([endless] * 3))      # > 2048 beats per opcode, never a reset
+    want, state = oracle.eval_bundles("B", endless.view(oracle.IN_BUNDLE).reshape(-1), extended=True)
+    d_in = torch.from_numpy(endless.view(np.int32)).cuda()
+    d_out = torch.empty((endless.shape[0], 21), dtype=torch.int32, device="cuda")
+    c.eval_bundles_device(d_in, d_out)
+    assert_bits_equal(d_out.cpu().numpy().view(u32), want.view(u32).reshape(-1, 21), "endless pair")
+    assert tuple(int(x) for x in c.get_accum().view(u32)) == state
     c.close()
