@@ -46,7 +46,7 @@ struct rt_dp_ctx {
     hipStream_t stream = nullptr;
     // accumulator registers live in HBM; two copies so that the workgroup that
     // reads the incoming value never races the one that writes the outgoing one
-    float *d_state = nullptr;  // [2][4]: {euclid, dot, norm, pad}
+    float *d_state = nullptr;  // [3][4]: {euclid, dot, norm, pad}; copies 0 / 1 alternate, copy 2 is a call's backup
     int cur = 0;               // which copy is current
     // grow-only staging for host-pointer batches
     char *d_stage = nullptr;
@@ -308,8 +308,8 @@ int rt_dp_create(const rt_dp_config *cfg, rt_dp_ctx **out) {
     ctx->tuning.variant = env_int("RT_DP_VARIANT", 0);
     ctx->tuning.vec_passes = env_int("RT_DP_VEC_PASSES", 0);
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc(&ctx->d_state, 8 * sizeof(float));
-    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_state, 0, 8 * sizeof(float), ctx->stream);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_state, 12 * sizeof(float));
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_state, 0, 12 * sizeof(float), ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         int rc = fail(RT_DP_EHIP, "context set-up failed: %s", hipGetErrorString(e));
@@ -436,22 +436,38 @@ int rt_dp_eval_bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt
     if (ctx->stream_mode == 2 && !aligned16) return fail(RT_DP_EALIGN, "the fused record-stream path needs 16-byte aligned record arrays");
     if (ctx->stream_mode == 2 || (ctx->stream_mode == 0 && aligned16)) {
         // one pass over the records: evaluate in place, then add up the distance beats in stream order
-        int rc = grow(ctx->d_stream, ctx->stream_bytes, stream_fused_workspace(n));
+        // in pieces of 2^26 records, which bounds the workspace (12 bytes per record of a piece); smaller pieces
+        // measured slower (2^20: -17 %), the per-piece launches cost more than cache residency returns
+        const int lg = env_int("RT_DP_STREAM_CHUNK_LOG2", 26);
+        const uint64_t chunk = 1ull << (lg < 11 ? 11 : (lg > 30 ? 30 : lg));
+        const uint64_t first = n < chunk ? n : chunk;
+        int rc = grow(ctx->d_stream, ctx->stream_bytes, stream_fused_workspace(first));
         if (rc != RT_DP_OK) return rc;
         StreamSideView view;
+        const uint32_t *in_words = reinterpret_cast<const uint32_t *>(d_in);
         uint32_t *out_words = reinterpret_cast<uint32_t *>(d_out);
-        HIP_TRY(stream_fused_eval(reinterpret_cast<const uint32_t *>(d_in), n, ctx->extended ? 1 : 0, out_words, ctx->d_stream, &view, s));
-        if (ctx->extended) {
-            float *cur = ctx->d_state + 4 * ctx->cur, *nxt = ctx->d_state + 4 * (ctx->cur ^ 1);
-            // registers of an opcode without beats in this stream are carried over unchanged
-            HIP_TRY(hipMemcpyAsync(nxt, cur, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
-            HIP_TRY(stream_fused_fold(view, n, cur, nxt, out_words, s));
+        const int cur0 = ctx->cur;
+        HIP_TRY(hipMemcpyAsync(ctx->d_state + 8, ctx->d_state + 4 * cur0, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));  // backup
+        HIP_TRY(stream_fused_begin(ctx->d_stream, first, s));
+        for (uint64_t off = 0; off < n; off += chunk) {
+            const uint64_t m = (n - off < chunk) ? (n - off) : chunk;
+            HIP_TRY(stream_fused_eval(in_words + off * 84, m, first, ctx->extended ? 1 : 0, out_words + off * 21, ctx->d_stream, &view, s));
+            if (ctx->extended) {
+                float *cur = ctx->d_state + 4 * ctx->cur, *nxt = ctx->d_state + 4 * (ctx->cur ^ 1);
+                // registers of an opcode without beats in this piece are carried over unchanged
+                HIP_TRY(hipMemcpyAsync(nxt, cur, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
+                HIP_TRY(stream_fused_fold(view, m, cur, nxt, out_words + off * 21, s));
+                ctx->cur ^= 1;
+            }
         }
         uint32_t bad = 0;
-        HIP_TRY(hipMemcpyAsync(&bad, view.flags, sizeof bad, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&bad, view.flags + 8, sizeof bad, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (bad) return fail(RT_DP_EOPCODE, "the record stream holds an opcode > 3; the RTL's opcode field is 2 bits wide");
-        if (ctx->extended) ctx->cur ^= 1;
+        if (bad) {  // the registers keep their values from before the call
+            ctx->cur = cur0;
+            HIP_TRY(hipMemcpy(ctx->d_state + 4 * cur0, ctx->d_state + 8, 4 * sizeof(float), hipMemcpyDeviceToDevice));
+            return fail(RT_DP_EOPCODE, "the record stream holds an opcode > 3; the RTL's opcode field is 2 bits wide");
+        }
         return RT_DP_OK;
     }
     const uint64_t nblk = (n + 255) / 256;

@@ -39,7 +39,7 @@ struct StreamSide {
     uint32_t *tag;        // [n]   opcode | reset << 2
     float *sum0, *sum1;   // [n]   tree sums of a distance beat (Euclidean: sum0; angular: dot, norm)
     uint32_t *rbits[2];   // [ceil(n / 2048)] bit b of word w: records [(32 w + b) * 64, +64) hold a reset of opcode 2 / 3
-    uint32_t *flags;      // [0] an opcode > 3 was seen, [1] opcode 2 present, [2] opcode 3 present
+    uint32_t *flags;      // [1] opcode 2 present, [2] opcode 3 present (per launch); [8] an opcode > 3 was seen (sticky)
 };
 
 __device__ __forceinline__ float tree16(const float (&s)[16]) {  // (i, i+8), (i, i+4), (i, i+2), (0, 1)
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__
         sum0 = tree8(s);
         sum1 = tree8(m);
     } else if (have) {
-        atomicOr(&side.flags[0], 1u);  // cannot occur in the RTL's 2-bit field
+        atomicOr(&side.flags[8], 1u);  // cannot occur in the RTL's 2-bit field
     }
 
     if (have) {
@@ -227,8 +227,10 @@ __device__ __forceinline__ uint64_t stream_boundary(const uint32_t *tag, const u
     }
 }
 
-constexpr int kFoldThreads = 256;
-constexpr int kFoldSub = 1024;  // records per sub-tile
+constexpr int kFoldThreads = 64;   // one wave per workgroup: the fold is a chain of dependent memory round trips,
+constexpr int kFoldSub = 256;      // so many small workgroups in flight beat few large ones; records per sub-tile
+constexpr int kFoldWaves = kFoldThreads / 64;
+constexpr int kFoldPasses = kFoldSub / kFoldThreads;
 
 template <bool EUC>
 __device__ __forceinline__ void stream_fold(const uint32_t *__restrict__ tag, const float *__restrict__ sum0, const float *__restrict__ sum1,
@@ -238,14 +240,14 @@ __device__ __forceinline__ void stream_fold(const uint32_t *__restrict__ tag, co
     __shared__ float c_sum0[kFoldSub], c_sum1[EUC ? 1 : kFoldSub], c_out0[kFoldSub], c_out1[EUC ? 1 : kFoldSub];
     __shared__ uint16_t c_pos[kFoldSub];
     __shared__ uint8_t c_rs[kFoldSub];
-    __shared__ uint32_t s_cnt[kFoldSub / 64];
+    __shared__ uint32_t s_cnt[kFoldPasses * kFoldWaves];
     __shared__ uint64_t s_range[2];
     __shared__ float s_carry[2][2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (wave < 2) {
-        const uint64_t r = stream_boundary(tag, rbits, X | 4u, (uint64_t)(blockIdx.x + wave) * tile, n, lane);
-        if (lane == 0) s_range[wave] = r;
+    for (int e = wave; e < 2; e += kFoldWaves) {  // both ends of the range, by different waves where there are two
+        const uint64_t r = stream_boundary(tag, rbits, X | 4u, (uint64_t)(blockIdx.x + e) * tile, n, lane);
+        if (lane == 0) s_range[e] = r;
     }
     if (tid == 0) {  // only the workgroup that starts at record 0 can inherit a running sum
         s_carry[0][0] = (blockIdx.x == 0) ? state_in[0] : 0.0f;
@@ -259,21 +261,21 @@ __device__ __forceinline__ void stream_fold(const uint32_t *__restrict__ tag, co
     for (uint64_t base = lo; base < hi; base += kFoldSub) {
         const int cnt = (hi - base < (uint64_t)kFoldSub) ? (int)(hi - base) : kFoldSub;
         // compaction of the opcode's beats, in stream order: position p = u * 256 + tid
-        uint32_t tg[kFoldSub / kFoldThreads];
-        unsigned long long mk[kFoldSub / kFoldThreads];
+        uint32_t tg[kFoldPasses];
+        unsigned long long mk[kFoldPasses];
 #pragma unroll
-        for (int u = 0; u < kFoldSub / kFoldThreads; ++u) {
+        for (int u = 0; u < kFoldPasses; ++u) {
             const int p = u * kFoldThreads + tid;
             tg[u] = (p < cnt) ? tag[base + p] : 0xFFu;
             mk[u] = __ballot((tg[u] & 3u) == X && tg[u] != 0xFFu);
-            if (lane == 0) s_cnt[u * 4 + wave] = (uint32_t)__popcll(mk[u]);
+            if (lane == 0) s_cnt[u * kFoldWaves + wave] = (uint32_t)__popcll(mk[u]);
         }
         __syncthreads();
         int m = 0;
 #pragma unroll
-        for (int u = 0; u < kFoldSub / kFoldThreads; ++u) {
+        for (int u = 0; u < kFoldPasses; ++u) {
             uint32_t before = 0;
-            for (int k = 0; k < u * 4 + wave; ++k) before += s_cnt[k];
+            for (int k = 0; k < u * kFoldWaves + wave; ++k) before += s_cnt[k];
             const int p = u * kFoldThreads + tid;
             if ((tg[u] & 3u) == X && tg[u] != 0xFFu) {
                 const uint32_t k = before + (uint32_t)__popcll(mk[u] & ((1ull << lane) - 1ull));
@@ -283,7 +285,7 @@ __device__ __forceinline__ void stream_fold(const uint32_t *__restrict__ tag, co
                 c_pos[k] = (uint16_t)p;
             }
         }
-        for (int k = 0; k < kFoldSub / 64; ++k) m += (int)s_cnt[k];
+        for (int k = 0; k < kFoldPasses * kFoldWaves; ++k) m += (int)s_cnt[k];
         __syncthreads();
         if (m == 0) continue;  // wave-uniform: no beat of this opcode here, the carry stays where it is
 
@@ -334,7 +336,7 @@ __device__ __forceinline__ void stream_fold(const uint32_t *__restrict__ tag, co
 
 // blockIdx.y = 0: Euclidean, 1: angular, side by side in one launch; an opcode that does not occur in
 // the stream (flags written by k_stream_eval) costs one load per workgroup.  state: {euclid, dot, norm}.
-__global__ __launch_bounds__(256) void k_stream_fold(StreamSideView v, uint64_t n, uint32_t tile, const float *__restrict__ state_in,
+__global__ __launch_bounds__(kFoldThreads) void k_stream_fold(StreamSideView v, uint64_t n, uint32_t tile, const float *__restrict__ state_in,
                                                      float *__restrict__ state_out, uint32_t *__restrict__ out) {
     if (blockIdx.y == 0) {
         if (v.flags[1]) stream_fold<true>(v.tag, v.sum0, v.sum1, v.rbits[0], n, tile, state_in, state_out, out);
@@ -343,26 +345,43 @@ __global__ __launch_bounds__(256) void k_stream_fold(StreamSideView v, uint64_t 
     }
 }
 
-size_t stream_fused_workspace(uint64_t n) {
-    const uint64_t nblk = (n + 63) / 64, nwords = (nblk + 31) / 32;
-    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
-    return 3 * up(n * 4) + 2 * up(nwords * 4) + 256;
-}
-
-hipError_t stream_fused_eval(const uint32_t *in, uint64_t n, int extended, uint32_t *out, char *workspace, StreamSideView *view, hipStream_t s) {
-    const uint64_t nblk = (n + 63) / 64, nwords = (nblk + 31) / 32;
+// Workspace for pieces of at most `capacity` records: tag, sum0, sum1, the two bit arrays, 256 bytes of flags.
+static StreamSide stream_fused_layout(char *workspace, uint64_t capacity, size_t *bits_bytes) {
+    const uint64_t nblk = (capacity + 63) / 64, nwords = (nblk + 31) / 32;
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     StreamSide side;
     size_t o = 0;
-    side.tag = reinterpret_cast<uint32_t *>(workspace + o); o += up(n * 4);
-    side.sum0 = reinterpret_cast<float *>(workspace + o); o += up(n * 4);
-    side.sum1 = reinterpret_cast<float *>(workspace + o); o += up(n * 4);
+    side.tag = reinterpret_cast<uint32_t *>(workspace + o); o += up(capacity * 4);
+    side.sum0 = reinterpret_cast<float *>(workspace + o); o += up(capacity * 4);
+    side.sum1 = reinterpret_cast<float *>(workspace + o); o += up(capacity * 4);
     side.rbits[0] = reinterpret_cast<uint32_t *>(workspace + o); o += up(nwords * 4);
     side.rbits[1] = reinterpret_cast<uint32_t *>(workspace + o); o += up(nwords * 4);
     side.flags = reinterpret_cast<uint32_t *>(workspace + o);
-    hipError_t e = hipMemsetAsync(side.rbits[0], 0, 2 * up(nwords * 4) + 256, s);  // both bit arrays and the flags
+    if (bits_bytes) *bits_bytes = 2 * up(nwords * 4);
+    return side;
+}
+
+size_t stream_fused_workspace(uint64_t capacity) {
+    size_t bits = 0;
+    const StreamSide side = stream_fused_layout(nullptr, capacity, &bits);
+    return static_cast<size_t>(reinterpret_cast<char *>(side.flags) - static_cast<char *>(nullptr)) + 256;
+}
+
+// Clears the sticky "opcode > 3" word; once per call, before the first piece.
+hipError_t stream_fused_begin(char *workspace, uint64_t capacity, hipStream_t s) {
+    const StreamSide side = stream_fused_layout(workspace, capacity, nullptr);
+    return hipMemsetAsync(side.flags, 0, 256, s);
+}
+
+// One piece of n <= capacity records.
+hipError_t stream_fused_eval(const uint32_t *in, uint64_t n, uint64_t capacity, int extended, uint32_t *out, char *workspace,
+                             StreamSideView *view, hipStream_t s) {
+    size_t bits = 0;
+    const StreamSide side = stream_fused_layout(workspace, capacity, &bits);
+    const uint64_t nblk = (n + 63) / 64;
+    if (n > capacity || nblk > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(side.rbits[0], 0, bits + 32, s);  // both bit arrays and the per-piece flags
     if (e != hipSuccess) return e;
-    if (nblk > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_stream_eval, dim3((unsigned)nblk), dim3(64), 0, s, in, n, extended, out, side);
     view->tag = side.tag; view->sum0 = side.sum0; view->sum1 = side.sum1;
     view->rbits[0] = side.rbits[0]; view->rbits[1] = side.rbits[1]; view->flags = side.flags;

@@ -26,6 +26,12 @@ for wl in box tri euclid angular; do
     run "valu_$wl" 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d "$OUT/pmc_valu_$wl" -- $BENCH --only $wl --steps 3 --warmup 1
     run "grbm_$wl" 120 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_grbm_$wl" -- $BENCH --only $wl --steps 3 --warmup 1
 done
+# the drivers above the op kernels: record stream (both modes), k-NN (exhaustive and tree), traversal (both walks)
+for spec in "stream1:--only stream --stream-mode 1" "stream2:--only stream --stream-mode 2" "knn_exhaustive:--only knn --knn-tree 0" \
+            "knn_tree:--only knn --knn-tree 1" "trace_dfs:--only trace" "trace_wavefront:--only trace --trace-wavefront 1"; do
+    name=${spec%%:*}; args=${spec#*:}
+    run "kt_$name" 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$name" -- python3 $ROOT/bench.py --steps 3 --warmup 1 $args
+done
 run fetch_membench 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_membench" -- "$ROOT/raytracer_amd/lib/membench" 1024
 run write_membench 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_membench" -- "$ROOT/raytracer_amd/lib/membench" 1024
 echo "profile passes done" | tee -a "$OUT/log.txt"

@@ -55,6 +55,24 @@ with open(os.path.join(PROF, tag + "_kernel_trace.md"), "w") as f:
         dd = d[1:] if len(d) > 1 else d
         f.write("| `%s` | %d | %d | %.1f | %.1f | %.1f |\n" % (k, grid, len(d), sum(dd) / len(dd) / 1e3, min(dd) / 1e3, max(dd) / 1e3))
 
+# ---- kernel traces of the drivers above the op kernels
+drivers = sorted(d for d in glob.glob(os.path.join(src, "kt_*")) if os.path.isdir(d))
+if drivers:
+    with open(os.path.join(PROF, tag + "_drivers_kernel_trace.md"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats of the drivers above the op kernels (%s)\n\n" % tag)
+        f.write("`python3 bench.py --steps 3 --warmup 1 <arguments>`; library kernels only (torch's own kernels omitted), all calls averaged.\n")
+        for d in drivers:
+            per = defaultdict(list)
+            for path in glob.glob(os.path.join(d, "*", "*kernel_trace.csv")):
+                with open(path, newline="") as fh:
+                    for r in csv.DictReader(fh):
+                        m = re.search(r"rtdp::(k_\w+)(<[^>]*>)?", r["Kernel_Name"])
+                        if m:
+                            per[m.group(1) + (m.group(2) or "")].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            f.write("\n## %s\n\n| kernel | calls | avg us | total ms |\n|---|---|---|---|\n" % os.path.basename(d)[3:])
+            for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+                f.write("| `%s` | %d | %.1f | %.2f |\n" % (k, len(v), sum(v) / len(v) / 1e3, sum(v) / 1e6))
+
 # ---- counters
 def pmc(pattern, counter):
     out = defaultdict(list)
