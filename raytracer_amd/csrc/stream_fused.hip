@@ -316,13 +316,13 @@ __device__ __forceinline__ void stream_fold(const uint32_t *__restrict__ tag, co
             }
         }
         __syncthreads();
-        for (int t0 = tid; t0 < m; t0 += kFoldThreads) {
+        for (int t0 = tid; t0 < m; t0 += kFoldThreads) {  // partial-line writes: without nt each one pulls its line into L2 first
             uint32_t *rec = out + (base + c_pos[t0]) * kRecOut;
             if (EUC) {
-                rec[16] = __float_as_uint(c_out0[t0]);
+                __builtin_nontemporal_store(__float_as_uint(c_out0[t0]), rec + 16);
             } else {
-                rec[18] = __float_as_uint(c_out0[t0]);
-                rec[19] = __float_as_uint(c_out1[t0]);
+                __builtin_nontemporal_store(__float_as_uint(c_out0[t0]), rec + 18);
+                __builtin_nontemporal_store(__float_as_uint(c_out1[t0]), rec + 19);
             }
         }
         par ^= 1;
