@@ -39,6 +39,9 @@ def parse():
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--log2-ops", type=int, default=24, help="ops per GPU of the headline box batch")
+    p.add_argument("--ops", type=int, default=0, help="ops per GPU when not a power of two (overrides --log2-ops)")
+    p.add_argument("--stagger-kib", type=int, default=0, help="box workload: operand arrays live in one allocation, array k shifted by k x this many KiB "
+                                                              "beyond its natural place, so that the arrays do not cross page boundaries together")
     p.add_argument("--ops-per-lane", type=int, default=0)
     p.add_argument("--nontemporal", type=int, default=0)
     p.add_argument("--vec-tile", type=int, default=0)
@@ -62,7 +65,7 @@ def parse():
     return p.parse_args()
 
 
-def make_batches(n, dev, which):
+def make_batches(n, dev, which, stagger_kib=0):
     """Resident operand / result arrays and one capi.Batch per workload."""
     out = {}
     i32, f32 = torch.int32, torch.float32
@@ -72,6 +75,16 @@ def make_batches(n, dev, which):
         tm = torch.empty(4, n_, dtype=f32, device=dev)
         tmin = [tm[0], tm[1], tm[2], tm[3]]
         flags = torch.empty(n_, dtype=i32, device=dev)
+        if stagger_kib:
+            pitch = n_ + (0 if stagger_kib < 0 else stagger_kib * 256)  # floats; a negative value: one pool, natural spacing
+            pool = torch.empty(39 * pitch + 64, dtype=f32, device=dev)
+            def place(k, t):
+                v = pool[k * pitch:k * pitch + n_]
+                v.copy_(t.view(f32) if t.dtype != f32 else t)
+                return v
+            fields = [place(k, f) for k, f in enumerate(fields)]
+            tmin = [pool[(34 + k) * pitch:(34 + k) * pitch + n_] for k in range(4)]
+            flags = pool[38 * pitch:38 * pitch + n_].view(i32)
         return fields, tmin, flags
 
     def tri(n_):
@@ -415,7 +428,7 @@ def main():
         dist_util.init("nccl")  # RCCL; a no-op for a single process
     dist = torch.distributed if world > 1 else None
     dev = torch.device("cuda", local)
-    n = 1 << a.log2_ops
+    n = a.ops if a.ops else 1 << a.log2_ops
 
     if a.only == "stream":
         run_stream(a, world, rank, local, dev)
@@ -428,11 +441,9 @@ def main():
         return
 
     which = [a.only] if a.only else ["box", "tri", "euclid", "angular", "mixed"]
-    if world > 1 and not a.only:
-        which = ["box"]
     ctx = capi.Context(device=local)
     ctx.set_tuning(a.ops_per_lane, a.nontemporal, a.vec_tile, a.variant, a.vec_passes)
-    batches = make_batches(n, dev, which)
+    batches = make_batches(n, dev, which, a.stagger_kib)
     torch.cuda.synchronize()
 
     if a.sweep:
@@ -451,13 +462,14 @@ def main():
 
     head = which[0]
     r = results[head]
+    size_text = ("%d" % a.ops) if a.ops else ("2^%d" % a.log2_ops)
     line = {
         "metric": "datapath ops/s per opcode (whole node)" if head == "box" else "datapath ops/s (%s)" % head,
         "value": round(r["value"], 1), "unit": "ops/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(r["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: 2^%d random ray-vs-4-AABB box ops per GPU, SoA fp32 operands resident in HBM" % (head, a.log2_ops)
-                   if head == "box" else "%s, 2^%d units per GPU" % (head, a.log2_ops),
+        "config": {"workload": "%s: %s random ray-vs-4-AABB box ops per GPU, SoA fp32 operands resident in HBM" % (head, size_text)
+                   if head == "box" else "%s, %s units per GPU" % (head, size_text),
                    "ops_per_gpu": r["units_per_gpu"], "bytes_per_op": BYTES.get(head), "sharding": "independent op streams per GPU, no collective",
                    "tuning": {"ops_per_lane": a.ops_per_lane, "nontemporal": a.nontemporal, "vec_tile": a.vec_tile, "variant": a.variant, "vec_passes": a.vec_passes}},
         "roofline": r["roofline"],
