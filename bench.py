@@ -57,7 +57,8 @@ def parse():
     p.add_argument("--trace-wavefront", type=int, default=0, help="1: breadth-first walk with queue compaction; 0: depth-first walk")
     p.add_argument("--trace-log2-tris", type=int, default=18)
     p.add_argument("--trace-log2-rays", type=int, default=22)
-    p.add_argument("--knn-tree", type=int, default=1, help="1: walk the k-d tree index with box pruning; 0: exhaustive scan")
+    p.add_argument("--knn-tree", type=int, default=2, help="1: walk the k-d tree index with box pruning; 2: leaf-major search on the same index; 0: exhaustive scan")
+    p.add_argument("--knn-walk", type=int, default=128, help="leaf-major search: leaves walked per query for the first bound")
     p.add_argument("--knn-data", default="uniform", help="uniform: U(-1,1)^16 (the named configuration); clustered: 256 Gaussian clusters, sigma 0.05")
     p.add_argument("--knn-leaf", type=int, default=128, help="points per tree leaf")
     p.add_argument("--knn-splits", type=int, default=0, help="point splits per query block (0 = chosen by the library front-end)")
@@ -388,7 +389,7 @@ def run_knn(a, world, rank, local, dev):
             dist_util.barrier()
             t0 = time.perf_counter()
             if tree is not None:
-                d, i = knn_tree.search(ctx, tree, qry, splits=a.knn_splits or None)
+                d, i = knn_tree.search(ctx, tree, qry, splits=a.knn_splits or None, grouped=(a.knn_tree == 2), walk_leaves=a.knn_walk)
             else:
                 d, i = knn.search(ctx, shard, qry, lo, splits=a.knn_splits or None)
             torch.cuda.synchronize()
@@ -405,7 +406,7 @@ def run_knn(a, world, rank, local, dev):
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "knn: 2^%d points sharded over %d GPU(s), 2^%d queries replicated, dim 16, k 16, %s data, one all-gather merge" % (
                               a.knn_log2_points, world, a.knn_log2_queries, a.knn_data)},
-                          "search": ("k-d tree walk with box pruning, leaf %d, index build %.1f ms (not timed)" % (a.knn_leaf, build_ms)) if a.knn_tree else "exhaustive",
+                          "search": ("k-d tree %s, leaf %d, index build %.1f ms (not timed)" % ("leaf-major search" if a.knn_tree == 2 else "walk with box pruning", a.knn_leaf, build_ms)) if a.knn_tree else "exhaustive",
                           "pair_rate_equivalent_per_s": round(pairs / per, 1),
                           "valu": None if a.knn_tree else {"lane_ops_per_pair": 48, "achieved_T_lane_ops": round(pairs * 48 / per / 1e12, 2), "peak_T_lane_ops": 78.6,
                                    "frac": round(pairs * 48 / per / 78.6e12, 4),

@@ -316,6 +316,23 @@ typedef struct rt_dp_knn_tree {
 int rt_dp_knn_tree_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, const float *queries, const uint32_t *home_leaf,
                             uint32_t n_queries, uint32_t splits, uint32_t *bound, float *out_dist, uint32_t *out_idx, void *hip_stream);
 
+/* The leaf-major form of the same search, for data whose neighbouring queries do not share
+ * their candidate leaves (e.g. uniform points in 16 dimensions, where the walk above prunes
+ * nothing per wave).  Same tree, same answers, one merged list per query:
+ *   1. the walk above, limited to the `walk_leaves` leaves nearest to each query, yields an upper
+ *      bound of each query's 16th distance;
+ *   2. per leaf, the queries whose box bound does not exceed their upper bound are listed;
+ *   3. per leaf and 64 listed queries the leaf's points are scanned; every (distance, index)
+ *      within the query's upper bound is kept as a candidate;
+ *   4. per query the 16 smallest candidates are selected; a query that filled its candidate slots
+ *      repeats 2-4 with the (tighter) 16th distance among the candidates it did collect.
+ * queries / home_leaf as above (sorted by home leaf).  out_dist / out_idx are [n_queries][16].
+ * Synchronous; scratch (lists and candidates: 8 KiB per query plus 4 bytes per listed pair) grows
+ * inside the context.  stats (may be NULL): {listed pairs, 64-query groups, slots per query,
+ * rounds}.  No counterpart in the reference.                                               */
+int rt_dp_knn_tree_grouped_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, const float *queries, const uint32_t *home_leaf,
+                                    uint32_t n_queries, uint32_t walk_leaves, float *out_dist, uint32_t *out_idx, uint64_t stats[4]);
+
 /* ---- closest-hit traversal on the Quadbox and triangle ops ----------------------------
  * No counterpart in the reference's sources, which end at the datapath: this is the loop a
  * consumer runs around it.  The ops are those of UnifiedDatapath.scala (children sorted by

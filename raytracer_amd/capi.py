@@ -123,7 +123,7 @@ class KnnTree(C.Structure):
                 ("points", C.c_void_p), ("index", C.c_void_p), ("leaf_lo", C.c_void_p), ("leaf_hi", C.c_void_p)]
 
 EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize",
-           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_knn_tree_euclid16", "rt_dp_trace_closest", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
+           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
            "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
 
 
@@ -163,6 +163,7 @@ def load():
     L.rt_dp_ray_prepare.argtypes = [vp, C.POINTER(RayPrep), C.c_uint64, vp]
     L.rt_dp_knn_euclid16.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.rt_dp_knn_tree_euclid16.argtypes = [vp, C.POINTER(KnnTree), vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
+    L.rt_dp_knn_tree_grouped_euclid16.argtypes = [vp, C.POINTER(KnnTree), vp, vp, C.c_uint32, C.c_uint32, vp, vp, C.POINTER(C.c_uint64 * 4)]
     L.rt_dp_trace_closest.argtypes = [vp, C.POINTER(Bvh4), C.POINTER(vp * 3), C.POINTER(vp * 3), C.c_uint32, C.c_float, C.c_uint32, vp, vp,
                                       C.POINTER(C.c_uint64 * 4)]
     L.rt_dp_last_error.restype = C.c_char_p
@@ -370,6 +371,21 @@ class Context:
                      tree.leaf_lo.data_ptr(), tree.leaf_hi.data_ptr())
         _check(self._L.rt_dp_knn_tree_euclid16(self._h, C.byref(ct), queries.data_ptr(), home_leaf.data_ptr(), m, splits, bound.data_ptr(),
                                                out_dist.data_ptr(), out_idx.data_ptr(), C.c_void_p(stream) if stream else None))
+
+    def knn_tree_grouped_euclid16(self, tree, queries, home_leaf, out_dist, out_idx, walk_leaves=16):
+        """Leaf-major exact top-16 (torch CUDA tensors): queries [m,16] sorted by home_leaf [m]; out_dist / out_idx [m,16].
+        Returns {pairs, groups, candidate_slots, rounds}.  Synchronous."""
+        for t in (queries, home_leaf, out_dist, out_idx, tree.points, tree.index, tree.leaf_lo, tree.leaf_hi):
+            if not (t.is_cuda and t.is_contiguous()):
+                raise ValueError("knn_tree_grouped_euclid16 needs contiguous CUDA tensors")
+        m = int(queries.shape[0])
+        assert tuple(out_dist.shape) == (m, 16) and tuple(out_idx.shape) == (m, 16) and home_leaf.shape[0] == m
+        ct = KnnTree(C.sizeof(KnnTree), tree.n_leaves, tree.leaf_size, 0, tree.points.data_ptr(), tree.index.data_ptr(),
+                     tree.leaf_lo.data_ptr(), tree.leaf_hi.data_ptr())
+        stats = (C.c_uint64 * 4)()
+        _check(self._L.rt_dp_knn_tree_grouped_euclid16(self._h, C.byref(ct), queries.data_ptr(), home_leaf.data_ptr(), m, int(walk_leaves),
+                                                       out_dist.data_ptr(), out_idx.data_ptr(), C.byref(stats)))
+        return {"pairs": stats[0], "groups": stats[1], "candidate_slots": stats[2], "rounds": stats[3]}
 
     def trace_closest(self, nodes, tris, origin, direction, extent, out_t, out_tri, wavefront=False):
         """Closest hit of every ray in a 4-wide hierarchy (torch CUDA tensors).  nodes [m,32] float32, tris [n,12] float32,

@@ -59,6 +59,9 @@ struct rt_dp_ctx {
     size_t trace_bytes = 0;
     char *d_queue[3] = {nullptr, nullptr, nullptr};
     size_t queue_items[3] = {0, 0, 0};
+    // leaf-major k-NN: per-query / per-leaf tables, the (leaf, query) lists, the candidate slots
+    char *d_knn[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t knn_bytes[4] = {0, 0, 0, 0};
     Tuning tuning{0, 0, 0, 0, 0};
     int stream_mode = 0;  // record streams in HBM: 0 automatic, 1 partition by opcode first, 2 fused single pass
 };
@@ -328,6 +331,8 @@ void rt_dp_destroy(rt_dp_ctx *ctx) {
     if (ctx->d_stream) (void)hipFree(ctx->d_stream);
     if (ctx->d_trace) (void)hipFree(ctx->d_trace);
     for (char *q : ctx->d_queue)
+        if (q) (void)hipFree(q);
+    for (char *q : ctx->d_knn)
         if (q) (void)hipFree(q);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -600,7 +605,7 @@ int rt_dp_knn_tree_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, const fl
     while ((1u << log2_splits) < splits) ++log2_splits;
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
-    HIP_TRY(launch_knn_tree16(tree->points, tree->index, tree->leaf_lo, tree->leaf_hi, nl, ls, queries, home_leaf, n_queries, log2_splits, bound,
+    HIP_TRY(launch_knn_tree16(tree->points, tree->index, tree->leaf_lo, tree->leaf_hi, nl, ls, queries, home_leaf, n_queries, log2_splits, 0, bound,
                               out_dist, out_idx, hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
     return RT_DP_OK;
 }
@@ -618,6 +623,126 @@ int regrow(char *&buf, size_t &have, size_t want, const char *what) {
 }
 
 }  // namespace
+
+int rt_dp_knn_tree_grouped_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, const float *queries, const uint32_t *home_leaf,
+                                    uint32_t n_queries, uint32_t walk_leaves, float *out_dist, uint32_t *out_idx, uint64_t stats[4]) {
+    if (!ctx || !tree) return fail(RT_DP_ENULL, "rt_dp_knn_tree_grouped_euclid16: NULL argument");
+    if (tree->struct_size != sizeof(rt_dp_knn_tree)) return fail(RT_DP_EINVAL, "rt_dp_knn_tree.struct_size does not match this library");
+    if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    if (n_queries == 0) return RT_DP_OK;
+    if (!queries || !home_leaf || !out_dist || !out_idx || !tree->points || !tree->index || !tree->leaf_lo || !tree->leaf_hi)
+        return fail(RT_DP_ENULL, "rt_dp_knn_tree_grouped_euclid16: NULL array");
+    const uint32_t nl = tree->n_leaves, ls = tree->leaf_size;
+    if (nl == 0 || (nl & (nl - 1))) return fail(RT_DP_EINVAL, "n_leaves = %u is not a power of two", nl);
+    if (ls == 0 || (ls & 3u)) return fail(RT_DP_EINVAL, "leaf_size = %u is not a positive multiple of 4", ls);
+    if ((uint64_t)nl * ls > 0xFFFFFFFFull) return fail(RT_DP_EINVAL, "n_leaves * leaf_size exceeds the 32-bit slot range");
+    if ((reinterpret_cast<uintptr_t>(tree->points) | reinterpret_cast<uintptr_t>(tree->leaf_lo) | reinterpret_cast<uintptr_t>(tree->leaf_hi) |
+         reinterpret_cast<uintptr_t>(queries)) & 7u)
+        return fail(RT_DP_EALIGN, "rt_dp_knn_tree_grouped_euclid16: coordinate arrays must be 8-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(tree->index) | reinterpret_cast<uintptr_t>(home_leaf) | reinterpret_cast<uintptr_t>(out_dist) |
+         reinterpret_cast<uintptr_t>(out_idx)) & 3u)
+        return fail(RT_DP_EALIGN, "rt_dp_knn_tree_grouped_euclid16: arrays must be 4-byte aligned");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipDeviceSynchronize());  // the caller's arrays may still be in flight on other streams
+    const KnnTreeView view{tree->points, tree->index, tree->leaf_lo, tree->leaf_hi, nl, ls};
+    const uint64_t nq = n_queries;
+
+    // tables: tau[nq] | n_cand[nq] | overflow[nq] | count[nl] | offset[nl] | group_first[nl]
+    const size_t o_tau = 0, o_nc = align_up(nq * 4), o_ov = o_nc + align_up(nq * 4), o_cnt = o_ov + align_up(nq * 4);
+    const size_t o_off = o_cnt + align_up((size_t)nl * 4), o_gf = o_off + align_up((size_t)nl * 4), tables = o_gf + align_up((size_t)nl * 4);
+    int rc = regrow(ctx->d_knn[0], ctx->knn_bytes[0], tables, "k-NN tables");
+    if (rc != RT_DP_OK) return rc;
+    char *tb = ctx->d_knn[0];
+    uint32_t *tau = reinterpret_cast<uint32_t *>(tb + o_tau), *n_cand = reinterpret_cast<uint32_t *>(tb + o_nc);
+    uint32_t *overflow = reinterpret_cast<uint32_t *>(tb + o_ov), *count = reinterpret_cast<uint32_t *>(tb + o_cnt);
+    uint32_t *offset = reinterpret_cast<uint32_t *>(tb + o_off), *group_first = reinterpret_cast<uint32_t *>(tb + o_gf);
+
+    // 1. upper bounds: the wave walk over the nearest leaves only; its lists land in the output arrays and are overwritten later
+    HIP_TRY(launch_knn_tree16(view.pts, view.index, view.leaf_lo, view.leaf_hi, nl, ls, queries, home_leaf, n_queries, 0,
+                              walk_leaves ? walk_leaves : 16u, tau, out_dist, out_idx, s));
+    // Rounds of: per-leaf query lists (count, prefix sums on the host, fill), scan, select.  Queries that fill
+    // their candidate slots go into another round with a tighter bound; everything else is settled.
+    uint64_t cap = 1024, pairs_total = 0, groups_total = 0, rounds = 0;
+    const uint64_t slots = (uint64_t)nl * ls;
+    std::vector<uint32_t> h_count(nl), h_off(nl), h_gf(nl), continuing;
+    for (;;) {
+        ++rounds;
+        if (cap > slots) cap = slots;
+        if (nq * cap * 8 > (64ull << 30)) return fail(RT_DP_ENOMEM, "candidate slots would need %llu GiB: use rt_dp_knn_tree_euclid16 for this data",
+                                                      (unsigned long long)((nq * cap * 8) >> 30));
+        // round 1 covers every query and remembers its box-test ballots (8 bytes per wave and leaf) for the fill pass;
+        // later rounds cover the few queries that continue
+        const uint32_t *subset = nullptr;
+        uint32_t n_sub = n_queries;
+        unsigned long long *masks = nullptr;
+        if (rounds == 1) {
+            const size_t mask_bytes = (size_t)((nq + 63) / 64) * nl * 8;
+            if (mask_bytes <= (8ull << 30)) {
+                rc = regrow(ctx->d_knn[3], ctx->knn_bytes[3], mask_bytes, "k-NN ballots");
+                if (rc != RT_DP_OK) return rc;
+                masks = reinterpret_cast<unsigned long long *>(ctx->d_knn[3]);
+            }
+        } else {
+            rc = regrow(ctx->d_knn[3], ctx->knn_bytes[3], continuing.size() * 4, "k-NN subset");
+            if (rc != RT_DP_OK) return rc;
+            HIP_TRY(hipMemcpyAsync(ctx->d_knn[3], continuing.data(), continuing.size() * 4, hipMemcpyHostToDevice, s));
+            subset = reinterpret_cast<const uint32_t *>(ctx->d_knn[3]);
+            n_sub = (uint32_t)continuing.size();
+        }
+        HIP_TRY(hipMemsetAsync(count, 0, (size_t)nl * 4, s));
+        HIP_TRY(launch_knn_pairs(view, queries, subset, n_sub, tau, count, nullptr, nullptr, masks, s));
+        HIP_TRY(hipMemcpyAsync(h_count.data(), count, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        uint64_t pairs = 0, groups = 0;
+        for (uint32_t l = 0; l < nl; ++l) {
+            h_off[l] = (uint32_t)pairs;
+            h_gf[l] = (uint32_t)groups;
+            pairs += h_count[l];
+            groups += (h_count[l] + 63u) / 64u;
+            if (pairs > 0xFFFFFFFFull) return fail(RT_DP_ENOMEM, "more than 2^32 (leaf, query) pairs: use rt_dp_knn_tree_euclid16 for this data");
+        }
+        pairs_total += pairs;
+        groups_total += groups;
+        rc = regrow(ctx->d_knn[1], ctx->knn_bytes[1], align_up(pairs * 4) + align_up(groups * 4) + 256, "k-NN lists");
+        if (rc != RT_DP_OK) return rc;
+        rc = regrow(ctx->d_knn[2], ctx->knn_bytes[2], nq * cap * 8, "k-NN candidates");
+        if (rc != RT_DP_OK) return rc;
+        uint32_t *list = reinterpret_cast<uint32_t *>(ctx->d_knn[1]);
+        uint32_t *group_leaf = reinterpret_cast<uint32_t *>(ctx->d_knn[1] + align_up(pairs * 4));
+        unsigned long long *cand = reinterpret_cast<unsigned long long *>(ctx->d_knn[2]);
+        HIP_TRY(hipMemcpyAsync(offset, h_off.data(), (size_t)nl * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(group_first, h_gf.data(), (size_t)nl * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(count, 0, (size_t)nl * 4, s));
+        HIP_TRY(launch_knn_pairs(view, queries, subset, n_sub, tau, count, offset, list, masks, s));
+        HIP_TRY(launch_knn_groups(group_first, count, nl, group_leaf, s));
+        HIP_TRY(hipMemsetAsync(n_cand, 0, 2 * align_up(nq * 4), s));  // n_cand and overflow
+        HIP_TRY(launch_knn_leaf_scan(view, queries, tau, (uint32_t)groups, group_leaf, group_first, count, offset, list, (uint32_t)cap, n_cand, cand, s));
+        HIP_TRY(launch_knn_select(tau, n_cand, cand, (uint32_t)cap, n_queries, out_dist, out_idx, overflow, s));
+        HIP_TRY(hipMemsetAsync(group_first, 0, 8, s));  // re-used as the round's status words
+        HIP_TRY(launch_knn_retau(tau, overflow, out_dist, n_queries, group_first, s));
+        uint32_t status[2];
+        HIP_TRY(hipMemcpyAsync(status, group_first, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (status[0] == 0) break;
+        {  // the queries that continue: those whose bound is still a distance (not -Inf)
+            std::vector<uint32_t> h_tau(nq);
+            HIP_TRY(hipMemcpy(h_tau.data(), tau, nq * 4, hipMemcpyDeviceToHost));
+            continuing.clear();
+            for (uint32_t i = 0; i < n_queries; ++i)
+                if (h_tau[i] != 0xFF800000u) continuing.push_back(i);
+        }
+        if (status[1]) {  // more equal-distance candidates than slots: only more slots help
+            if (cap == slots) return fail(RT_DP_EHIP, "internal error: candidate slots cover every point and still overflow");
+            cap *= 4;
+        }
+        if (rounds > 64) return fail(RT_DP_EHIP, "internal error: the leaf-major search does not converge");
+    }
+    const uint64_t pairs = pairs_total, groups = groups_total;
+    if (stats) { stats[0] = pairs; stats[1] = groups; stats[2] = cap; stats[3] = rounds; }
+    return RT_DP_OK;
+}
 
 int rt_dp_trace_closest(rt_dp_ctx *ctx, const rt_dp_bvh4 *bvh, const float *const origin[3], const float *const dir[3],
                         uint32_t n_rays, float extent, uint32_t flags, float *out_t, uint32_t *out_tri, uint64_t stats[4]) {

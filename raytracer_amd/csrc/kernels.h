@@ -94,7 +94,22 @@ hipError_t trace_dfs(const float *const origin[3], const float *const dir[3], ui
                      float *out_t, uint32_t *out_tri, unsigned long long *totals, uint32_t *overflow, hipStream_t s);
 hipError_t trace_finish(const unsigned long long *best, uint32_t n, float *out_t, uint32_t *out_tri, hipStream_t s);
 hipError_t launch_knn_tree16(const float *pts, const uint32_t *index, const float *leaf_lo, const float *leaf_hi, uint32_t n_leaves,
-                             uint32_t leaf_size, const float *qry, const uint32_t *home, uint32_t n_qry, uint32_t log2_splits,
+                             uint32_t leaf_size, const float *qry, const uint32_t *home, uint32_t n_qry, uint32_t log2_splits, uint32_t walk,
                              uint32_t *bound, float *out_d, uint32_t *out_i, hipStream_t stream);
+struct KnnTreeView {
+    const float *pts;
+    const uint32_t *index;
+    const float *leaf_lo, *leaf_hi;
+    uint32_t n_leaves, leaf_size;
+};
+hipError_t launch_knn_groups(const uint32_t *group_first, const uint32_t *count, uint32_t n_leaves, uint32_t *group_leaf, hipStream_t stream);
+hipError_t launch_knn_pairs(const KnnTreeView &t, const float *qry, const uint32_t *subset, uint32_t n_qry, const uint32_t *tau,
+                            uint32_t *count, const uint32_t *offset, uint32_t *list, unsigned long long *masks, hipStream_t stream);
+hipError_t launch_knn_leaf_scan(const KnnTreeView &t, const float *qry, const uint32_t *tau, uint32_t n_groups, const uint32_t *group_leaf,
+                                const uint32_t *group_first, const uint32_t *count, const uint32_t *offset, const uint32_t *list,
+                                uint32_t cap, uint32_t *n_cand, unsigned long long *cand, hipStream_t stream);
+hipError_t launch_knn_select(const uint32_t *tau, const uint32_t *n_cand, const unsigned long long *cand, uint32_t cap, uint32_t n_qry,
+                             float *out_d, uint32_t *out_i, uint32_t *overflow, hipStream_t stream);
+hipError_t launch_knn_retau(uint32_t *tau, const uint32_t *overflow, const float *out_d, uint32_t n_qry, uint32_t *status, hipStream_t stream);
 
 }  // namespace rtdp

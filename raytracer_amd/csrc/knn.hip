@@ -149,6 +149,7 @@ struct KnnTreeArgs {
     const uint32_t *index;
     const float *leaf_lo, *leaf_hi;
     uint32_t n_leaves, leaf_size, log2_splits;
+    uint32_t walk;  // leaves visited per split, nearest subtree first (0 = all of them)
 };
 
 __global__ __launch_bounds__(256) void k_knn_tree16(KnnTreeArgs tree, const float *__restrict__ qry, const uint32_t *__restrict__ home,
@@ -175,7 +176,8 @@ __global__ __launch_bounds__(256) void k_knn_tree16(KnnTreeArgs tree, const floa
     const uint32_t hh = __builtin_amdgcn_readfirstlane(home[qq]) >> tree.log2_splits;  // the wave follows its first query
     const f2v *pts2 = reinterpret_cast<const f2v *>(tree.pts);
 
-    for (uint32_t t = 0; t < per_split; ++t) {
+    const uint32_t n_walk = (tree.walk && tree.walk < per_split) ? tree.walk : per_split;
+    for (uint32_t t = 0; t < n_walk; ++t) {
         const uint32_t leaf = ((hh ^ t) << tree.log2_splits) | split;  // wave-uniform
         const f2v *lo = reinterpret_cast<const f2v *>(tree.leaf_lo) + (size_t)leaf * 8;
         const f2v *hi = reinterpret_cast<const f2v *>(tree.leaf_hi) + (size_t)leaf * 8;
@@ -215,14 +217,219 @@ __global__ __launch_bounds__(256) void k_knn_tree16(KnnTreeArgs tree, const floa
 }
 
 hipError_t launch_knn_tree16(const float *pts, const uint32_t *index, const float *leaf_lo, const float *leaf_hi, uint32_t n_leaves,
-                             uint32_t leaf_size, const float *qry, const uint32_t *home, uint32_t n_qry, uint32_t log2_splits,
+                             uint32_t leaf_size, const float *qry, const uint32_t *home, uint32_t n_qry, uint32_t log2_splits, uint32_t walk,
                              uint32_t *bound, float *out_d, uint32_t *out_i, hipStream_t stream) {
     if (n_qry == 0) return hipSuccess;
     hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(bound), 0x7F800000, n_qry, stream);  // +Inf: nothing known yet
     if (e != hipSuccess) return e;
-    KnnTreeArgs tree{pts, index, leaf_lo, leaf_hi, n_leaves, leaf_size, log2_splits};
+    KnnTreeArgs tree{pts, index, leaf_lo, leaf_hi, n_leaves, leaf_size, log2_splits, walk};
     dim3 grid((n_qry + 255) / 256, 1u << log2_splits);
     hipLaunchKernelGGL(k_knn_tree16, grid, dim3(256), 0, stream, tree, qry, home, n_qry, bound, out_d, out_i);
+    return hipGetLastError();
+}
+
+// ---- leaf-major search ------------------------------------------------------------------
+// Where neighbouring queries do not share their candidate leaves (uniform data in 16
+// dimensions: a query needs ~27 % of the leaves, 64 neighbouring queries together 99 %),
+// pruning per wave of queries saves nothing.  The leaf-major form turns the loop around:
+//   1. bound     k_knn_tree16 over the few leaves nearest to each query leaves tau_q, the
+//                16th distance found so far: an upper bound of the final 16th distance.
+//   2. lists     k_knn_pairs (count, then fill): for every leaf the queries whose deflated
+//                box bound does not exceed their tau_q, compacted per wave with a ballot.
+//   3. scan      k_knn_leaf_scan: one wave per 64 queries of one leaf's list; the leaf's
+//                points arrive as scalar operands exactly as in the kernels above; every
+//                (distance, index) with distance <= tau_q goes to that query's candidate
+//                slots (one atomic counter per query).
+//   4. select    k_knn_select: one wave per query keeps the 16 smallest candidate keys.
+// Every point within tau_q of its query lies in a listed leaf (same box-bound argument as
+// above) and passes the distance filter, and the final list is made of points within the
+// final 16th distance <= tau_q: the result is the exhaustive result, bit for bit.  A query
+// that collects more candidates than it has slots is flagged for the exhaustive kernel.
+// Two passes over (query, leaf): the first counts per leaf, the second, with count[] restarted from 0 as the
+// cursor, fills the lists.  `subset` (or NULL) names the queries of a later round.  `masks` (or NULL), one
+// 64-bit ballot per wave and leaf, carries the first pass's decisions to the second, which then skips the box test.
+__global__ __launch_bounds__(256) void k_knn_pairs(KnnTreeArgs tree, const float *__restrict__ qry, const uint32_t *__restrict__ subset,
+                                                  uint32_t n_qry, const uint32_t *__restrict__ tau, uint32_t *__restrict__ count,
+                                                  const uint32_t *__restrict__ offset, uint32_t *__restrict__ list,
+                                                  unsigned long long *__restrict__ masks) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool live = i < n_qry;
+    const uint32_t q = subset ? subset[live ? i : (n_qry - 1)] : (live ? i : (n_qry - 1));
+    const uint32_t l0 = blockIdx.y * (tree.n_leaves / gridDim.y), l1 = l0 + tree.n_leaves / gridDim.y;
+    // a wave that lies entirely behind the last query owns no row of the ballot array
+    unsigned long long *wave_masks = (masks && (i & ~63u) < n_qry) ? masks + (size_t)(i >> 6) * tree.n_leaves : nullptr;
+    if (masks && !wave_masks) return;
+    if (list && masks) {  // second pass with remembered decisions
+        for (uint32_t leaf = l0; leaf < l1; ++leaf) {
+            const unsigned long long m = wave_masks[leaf];  // wave-uniform
+            if (!m) continue;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(count + leaf, (uint32_t)__popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if ((m >> lane) & 1ull) list[offset[leaf] + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = q;
+        }
+        return;
+    }
+    f2v qv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) qv[k] = reinterpret_cast<const f2v *>(qry)[(size_t)q * 8 + k];
+    const float thr = __uint_as_float(tau[q]);
+    for (uint32_t leaf = l0; leaf < l1; ++leaf) {
+        const f2v *lo = reinterpret_cast<const f2v *>(tree.leaf_lo) + (size_t)leaf * 8;
+        const f2v *hi = reinterpret_cast<const f2v *>(tree.leaf_hi) + (size_t)leaf * 8;
+        float lb = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f2v a = lo[k] - qv[k], b = qv[k] - hi[k];
+            const float gx = fmaxf(fmaxf(a.x, b.x), 0.0f), gy = fmaxf(fmaxf(a.y, b.y), 0.0f);
+            lb += gx * gx;
+            lb += gy * gy;
+        }
+        const float lbd = lb * 0.9999847412109375f - 1.8807909613156600e-37f;  // (1 - 2^-16), 2^-122
+        const bool need = live && (lbd <= thr);
+        const unsigned long long m = __ballot(need);
+        if (wave_masks && lane == 0) wave_masks[leaf] = m;
+        if (!m) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(count + leaf, (uint32_t)__popcll(m));
+        if (list) {
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (need) list[offset[leaf] + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = q;
+        }
+    }
+}
+
+// group_leaf[g] = the leaf of work group g; groups of one leaf are consecutive, group_first[leaf] is its first.
+__global__ __launch_bounds__(64) void k_knn_leaf_scan(KnnTreeArgs tree, const float *__restrict__ qry, const uint32_t *__restrict__ tau,
+                                                     const uint32_t *__restrict__ group_leaf, const uint32_t *__restrict__ group_first,
+                                                     const uint32_t *__restrict__ count, const uint32_t *__restrict__ offset,
+                                                     const uint32_t *__restrict__ list, uint32_t cap, uint32_t *__restrict__ n_cand,
+                                                     unsigned long long *__restrict__ cand) {
+    const int lane = threadIdx.x;
+    const uint32_t g = blockIdx.x;
+    const uint32_t leaf = group_leaf[g];
+    const uint32_t k0 = (g - group_first[leaf]) * 64u;  // position of this group inside the leaf's list
+    const uint32_t have = count[leaf] - k0;             // >= 1 by construction
+    const bool live = (uint32_t)lane < have;
+    const uint32_t q = list[offset[leaf] + k0 + (live ? lane : 0)];
+    f2v qv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) qv[k] = reinterpret_cast<const f2v *>(qry)[(size_t)q * 8 + k];
+    const float thr = live ? __uint_as_float(tau[q]) : __uint_as_float(0xFF800000u);  // -Inf: nothing passes
+    const f2v *p = reinterpret_cast<const f2v *>(tree.pts) + (size_t)leaf * tree.leaf_size * 8;
+    const uint32_t *ix = tree.index + (size_t)leaf * tree.leaf_size;
+    for (uint32_t j = 0; j < tree.leaf_size; j += kKnnUnroll) {
+        float dist[kKnnUnroll];
+#pragma unroll
+        for (int u = 0; u < kKnnUnroll; ++u) dist[u] = knn_pair(qv, p + (size_t)(j + u) * 8);
+#pragma unroll
+        for (int u = 0; u < kKnnUnroll; ++u) {
+            const bool pass = dist[u] <= thr;  // false for NaN
+            if (__any(pass)) {
+                if (pass) {
+                    const uint32_t slot = atomicAdd(n_cand + q, 1u);
+                    if (slot < cap) cand[(size_t)q * cap + slot] = ((unsigned long long)__float_as_uint(dist[u]) << 32) | ix[j + u];
+                }
+            }
+        }
+    }
+}
+
+// One wave per query: the 16 smallest candidate keys, ascending; a key is distance bits << 32 | index and
+// distances are non-negative, so key order is (distance, index) order.  More candidates than slots: flagged.
+__global__ __launch_bounds__(64) void k_knn_select(const uint32_t *__restrict__ tau, const uint32_t *__restrict__ n_cand,
+                                                  const unsigned long long *__restrict__ cand, uint32_t cap, uint32_t n_qry, float *__restrict__ out_d, uint32_t *__restrict__ out_i,
+                                                  uint32_t *__restrict__ overflow) {
+    constexpr unsigned long long kNone = 0x7F800000FFFFFFFFull;
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (tau[q] == 0xFF800000u) return;  // settled in an earlier round
+    const uint32_t total = n_cand[q];
+    const uint32_t n = total < cap ? total : cap;
+    if (total > cap && lane == 0) overflow[q] = 1u;
+    unsigned long long mine = kNone;  // smallest key not yet taken among this lane's share (keys lane, lane + 64, ...)
+    auto refill = [&](unsigned long long above, bool first) {
+        unsigned long long best = kNone;
+        for (uint32_t k = lane; k < n; k += 64) {
+            const unsigned long long v = cand[(size_t)q * cap + k];
+            if ((first || v > above) && v < best) best = v;
+        }
+        return best;
+    };
+    mine = refill(0ull, true);
+    for (int t = 0; t < kTopK; ++t) {
+        unsigned long long w = mine;
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(w, off);
+            w = (o < w) ? o : w;
+        }
+        if (lane == 0) {
+            out_d[(size_t)q * kTopK + t] = __uint_as_float((uint32_t)(w >> 32));
+            out_i[(size_t)q * kTopK + t] = (uint32_t)w;
+        }
+        if (mine == w && w != kNone) mine = refill(w, false);  // keys are unique (one per point), so exactly one lane owns w
+    }
+}
+
+__global__ __launch_bounds__(256) void k_knn_groups(const uint32_t *__restrict__ group_first, const uint32_t *__restrict__ count,
+                                                   uint32_t n_leaves, uint32_t *__restrict__ group_leaf) {
+    const uint32_t leaf = blockIdx.x * 256u + threadIdx.x;
+    if (leaf >= n_leaves) return;
+    const uint32_t g0 = group_first[leaf], g1 = g0 + (count[leaf] + 63u) / 64u;
+    for (uint32_t g = g0; g < g1; ++g) group_leaf[g] = leaf;
+}
+
+hipError_t launch_knn_groups(const uint32_t *group_first, const uint32_t *count, uint32_t n_leaves, uint32_t *group_leaf, hipStream_t stream) {
+    hipLaunchKernelGGL(k_knn_groups, dim3((n_leaves + 255) / 256), dim3(256), 0, stream, group_first, count, n_leaves, group_leaf);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn_pairs(const KnnTreeView &t, const float *qry, const uint32_t *subset, uint32_t n_qry, const uint32_t *tau,
+                            uint32_t *count, const uint32_t *offset, uint32_t *list, unsigned long long *masks, hipStream_t stream) {
+    if (n_qry == 0) return hipSuccess;
+    KnnTreeArgs tree{t.pts, t.index, t.leaf_lo, t.leaf_hi, t.n_leaves, t.leaf_size, 0, 0};
+    uint32_t ysplit = 1;
+    while (ysplit * 2 <= t.n_leaves && ysplit < 16) ysplit *= 2;  // more workgroups for small query sets
+    hipLaunchKernelGGL(k_knn_pairs, dim3((n_qry + 255) / 256, ysplit), dim3(256), 0, stream, tree, qry, subset, n_qry, tau, count, offset, list,
+                       masks);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn_leaf_scan(const KnnTreeView &t, const float *qry, const uint32_t *tau, uint32_t n_groups, const uint32_t *group_leaf,
+                                const uint32_t *group_first, const uint32_t *count, const uint32_t *offset, const uint32_t *list,
+                                uint32_t cap, uint32_t *n_cand, unsigned long long *cand, hipStream_t stream) {
+    if (n_groups == 0) return hipSuccess;
+    KnnTreeArgs tree{t.pts, t.index, t.leaf_lo, t.leaf_hi, t.n_leaves, t.leaf_size, 0, 0};
+    hipLaunchKernelGGL(k_knn_leaf_scan, dim3(n_groups), dim3(64), 0, stream, tree, qry, tau, group_leaf, group_first, count, offset, list, cap,
+                       n_cand, cand);
+    return hipGetLastError();
+}
+
+// After a round: a query that filled its slots continues with the 16th distance among the candidates it did
+// collect (real points, so still an upper bound, and tighter); every other query is settled (tau = -Inf lists it
+// nowhere).  status[0] counts the queries that continue, status[1] those whose bound did not move.
+__global__ __launch_bounds__(256) void k_knn_retau(uint32_t *__restrict__ tau, const uint32_t *__restrict__ overflow, const float *__restrict__ out_d,
+                                                  uint32_t n_qry, uint32_t *__restrict__ status) {
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= n_qry) return;
+    if (tau[q] == 0xFF800000u) return;
+    if (!overflow[q]) { tau[q] = 0xFF800000u; return; }
+    const uint32_t t = __float_as_uint(out_d[(size_t)q * kTopK + kTopK - 1]);
+    atomicAdd(&status[0], 1u);
+    if (t >= tau[q]) atomicAdd(&status[1], 1u);  // bit patterns of non-negative floats order like the floats
+    else tau[q] = t;
+}
+
+hipError_t launch_knn_select(const uint32_t *tau, const uint32_t *n_cand, const unsigned long long *cand, uint32_t cap, uint32_t n_qry,
+                             float *out_d, uint32_t *out_i, uint32_t *overflow, hipStream_t stream) {
+    if (n_qry == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_knn_select, dim3(n_qry), dim3(64), 0, stream, tau, n_cand, cand, cap, n_qry, out_d, out_i, overflow);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn_retau(uint32_t *tau, const uint32_t *overflow, const float *out_d, uint32_t n_qry, uint32_t *status, hipStream_t stream) {
+    hipLaunchKernelGGL(k_knn_retau, dim3((n_qry + 255) / 256), dim3(256), 0, stream, tau, overflow, out_d, n_qry, status);
     return hipGetLastError();
 }
 

@@ -101,7 +101,27 @@ def local_topk(ctx, tree, queries, splits=None, k=knn.TOPK, stream=None):
     return out
 
 
-def search(ctx, tree, queries, k=knn.TOPK, group=None, splits=None):
+def local_topk_grouped(ctx, tree, queries, k=knn.TOPK, walk_leaves=128, stats=None):
+    """The same keys as local_topk through the leaf-major search (for data on which the wave walk cannot prune)."""
+    m = int(queries.shape[0])
+    home = tree.home_leaf(queries)
+    order = home.argsort(stable=True)
+    qs = queries[order].contiguous()
+    hs = home[order].contiguous()
+    d = torch.empty(m, knn.TOPK, dtype=torch.float32, device=queries.device)
+    i = torch.empty(m, knn.TOPK, dtype=torch.int32, device=queries.device)
+    torch.cuda.current_stream().synchronize()
+    st = ctx.knn_tree_grouped_euclid16(tree, qs, hs, d, i, walk_leaves=walk_leaves)
+    if stats is not None:
+        stats.update(st)
+    keys = knn.pack_keys(d, i)[:, :k].contiguous()
+    out = torch.empty_like(keys)
+    out[order] = keys
+    return out
+
+
+def search(ctx, tree, queries, k=knn.TOPK, group=None, splits=None, grouped=False, walk_leaves=128):
     """Sharded exact k-NN through per-GPU trees: every rank holds the tree of its shard of the points
     (built with that shard's index_base); one all-gather merges the partial lists."""
-    return knn.unpack_keys(knn.all_gather_merge(local_topk(ctx, tree, queries, splits=splits, k=k), k, group))
+    keys = local_topk_grouped(ctx, tree, queries, k=k, walk_leaves=walk_leaves) if grouped else local_topk(ctx, tree, queries, splits=splits, k=k)
+    return knn.unpack_keys(knn.all_gather_merge(keys, k, group))

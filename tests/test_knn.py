@@ -108,6 +108,11 @@ def test_tree_search_equals_exhaustive_search(ctx, oracle, torch_cuda, cloud, n,
     tree = knn_tree.KnnTree(P, leaf_size=leaf, index_base=1000)
     got = knn_tree.local_topk(ctx, tree, Q, splits=splits)
     assert torch.equal(got, want)
+    for walk in (1, 16):  # the leaf-major search: same answers whatever the quality of its first bound
+        stats = {}
+        got = knn_tree.local_topk_grouped(ctx, tree, Q, walk_leaves=walk, stats=stats)
+        bad = (got != want).any(1).nonzero().flatten().tolist()
+        assert not bad, (stats, bad[:5])
     if n <= 5000:
         wd, wi = oracle.knn_bruteforce(pts, qry, 16, 1000)
         d, i = knn.unpack_keys(got)
