@@ -285,6 +285,17 @@ int rt_dp_ray_prepare(rt_dp_ctx *ctx, const rt_dp_ray_prep *rays, uint64_t n, vo
 int rt_dp_knn_euclid16(rt_dp_ctx *ctx, const float *points, uint32_t n_points, const float *queries, uint32_t n_queries,
                        uint32_t index_base, uint32_t splits, float *out_dist, uint32_t *out_idx, void *hip_stream);
 
+/* The same exhaustive search ranked by the angular op (UnifiedDatapath.scala:246-268, :420-453,
+ * :1028-1064): per pair, dot = sum q_i c_i and norm = sum c_i^2 exactly as two 8-element beats
+ * deliver them (mask 0xFF, reset on the second), then the step the RTL leaves to its consumer
+ * (IOSpec.scala:21-23): score = dot / sqrt(norm), both IEEE correctly rounded.  Largest score
+ * first, ties by lower index; a pair whose score is NaN (zero or NaN norm) is never listed.
+ * out_neg_score receives MINUS the score (-0 as +0), ascending, so that lists merge by the same
+ * (value, index) order as distances; unused slots hold (+Inf, 0xFFFFFFFF).  Needs the extended
+ * datapath.  Layouts, splits and stream as for rt_dp_knn_euclid16.                          */
+int rt_dp_knn_angular16(rt_dp_ctx *ctx, const float *points, uint32_t n_points, const float *queries, uint32_t n_queries,
+                        uint32_t index_base, uint32_t splits, float *out_neg_score, uint32_t *out_idx, void *hip_stream);
+
 /* The same search through a tree over the points (no counterpart in the reference, as
  * above).  The caller supplies a balanced partition of the points into n_leaves (a power of
  * two) leaves of leaf_size slots (a multiple of 4), stored leaf by leaf:

@@ -196,3 +196,29 @@ def knn_bruteforce(points, queries, k=16, index_base=0):
         out_d[q, :order.size] = d[ok][order]
         out_i[q, :order.size] = ids[ok][order]
     return out_d, out_i
+
+
+def knn_bruteforce_angular(points, queries, k=16, index_base=0):
+    """Exact top-k by the angular op: per pair, oracle B's two 8-element beats (mask 0xFF, reset on the second)
+    give dot and norm; score = dot / sqrt(norm) in float32 (numpy's sqrt and divide are correctly rounded).
+    Ranked by (larger score, lower index); NaN scores are excluded.  Returns (minus score [m, k] float32 with -0
+    written as +0, idx [m, k] int64), padded with (+Inf, 0xFFFFFFFF)."""
+    points = np.ascontiguousarray(points, np.float32)
+    queries = np.ascontiguousarray(queries, np.float32)
+    n, m = points.shape[0], queries.shape[0]
+    out_v = np.full((m, k), np.inf, np.float32)
+    out_i = np.full((m, k), 0xFFFFFFFF, np.int64)
+    ctl = np.tile(np.array([0xFF, 0x100FF], u32), n)
+    ids = np.arange(n, dtype=np.int64) + index_base
+    c = points.reshape(2 * n, 8)
+    for q in range(m):
+        qq = np.tile(queries[q].reshape(2, 8), (n, 1))
+        d, nm, _, _ = angular_beats(qq, c, ctl)
+        with np.errstate(all="ignore"):
+            neg = -(d[1::2] / np.sqrt(nm[1::2])).astype(np.float32)
+        neg = np.where(neg == 0, np.float32(0), neg).astype(np.float32)
+        ok = ~np.isnan(neg)
+        order = np.lexsort((ids[ok], neg[ok]))[:k]
+        out_v[q, :order.size] = neg[ok][order]
+        out_i[q, :order.size] = ids[ok][order]
+    return out_v, out_i

@@ -123,7 +123,7 @@ class KnnTree(C.Structure):
                 ("points", C.c_void_p), ("index", C.c_void_p), ("leaf_lo", C.c_void_p), ("leaf_hi", C.c_void_p)]
 
 EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize",
-           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
+           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_knn_angular16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
            "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
 
 
@@ -162,6 +162,7 @@ def load():
     L.rt_dp_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.rt_dp_ray_prepare.argtypes = [vp, C.POINTER(RayPrep), C.c_uint64, vp]
     L.rt_dp_knn_euclid16.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
+    L.rt_dp_knn_angular16.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.rt_dp_knn_tree_euclid16.argtypes = [vp, C.POINTER(KnnTree), vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     L.rt_dp_knn_tree_grouped_euclid16.argtypes = [vp, C.POINTER(KnnTree), vp, vp, C.c_uint32, C.c_uint32, vp, vp, C.POINTER(C.c_uint64 * 4)]
     L.rt_dp_trace_closest.argtypes = [vp, C.POINTER(Bvh4), C.POINTER(vp * 3), C.POINTER(vp * 3), C.c_uint32, C.c_float, C.c_uint32, vp, vp,
@@ -346,6 +347,16 @@ class Context:
         if keep != {"cuda"}:
             raise ValueError("ray_prepare needs CUDA tensors")
         _check(self._L.rt_dp_ray_prepare(self._h, C.byref(rp), int(dirs[0].shape[0]), C.c_void_p(stream) if stream else None))
+
+    def knn_angular16(self, points, queries, out_neg_score, out_idx, index_base=0, splits=1, stream=None):
+        """Top-16 points per query by the angular op's dot / sqrt(norm) (largest first); out_neg_score holds minus the score."""
+        for t in (points, queries, out_neg_score, out_idx):
+            if not (t.is_cuda and t.is_contiguous()):
+                raise ValueError("knn_angular16 needs contiguous CUDA tensors")
+        n, m = int(points.shape[0]), int(queries.shape[0])
+        assert tuple(out_neg_score.shape) == (splits, m, 16) and tuple(out_idx.shape) == (splits, m, 16)
+        _check(self._L.rt_dp_knn_angular16(self._h, points.data_ptr(), n, queries.data_ptr(), m, index_base, splits,
+                                           out_neg_score.data_ptr(), out_idx.data_ptr(), C.c_void_p(stream) if stream else None))
 
     def knn_euclid16(self, points, queries, out_dist, out_idx, index_base=0, splits=1, stream=None):
         """Top-16 nearest points per query (torch CUDA tensors): points [n,16], queries [m,16] float32,

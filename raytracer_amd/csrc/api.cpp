@@ -564,22 +564,38 @@ int rt_dp_ray_prepare(rt_dp_ctx *ctx, const rt_dp_ray_prep *rays, uint64_t n, vo
     return RT_DP_OK;
 }
 
-int rt_dp_knn_euclid16(rt_dp_ctx *ctx, const float *points, uint32_t n_points, const float *queries, uint32_t n_queries,
-                       uint32_t index_base, uint32_t splits, float *out_dist, uint32_t *out_idx, void *hip_stream) {
-    if (!ctx) return fail(RT_DP_ENULL, "rt_dp_knn_euclid16: ctx is NULL");
+namespace {
+
+int knn_exhaustive(rt_dp_ctx *ctx, const char *who, bool angular, const float *points, uint32_t n_points, const float *queries,
+                   uint32_t n_queries, uint32_t index_base, uint32_t splits, float *out_val, uint32_t *out_idx, void *hip_stream) {
+    if (!ctx) return fail(RT_DP_ENULL, "%s: ctx is NULL", who);
     if (n_queries == 0) return RT_DP_OK;
-    if (!queries || !out_dist || !out_idx || (n_points && !points)) return fail(RT_DP_ENULL, "rt_dp_knn_euclid16: NULL array");
+    if (!queries || !out_val || !out_idx || (n_points && !points)) return fail(RT_DP_ENULL, "%s: NULL array", who);
     if (splits == 0 || splits > 65535u) return fail(RT_DP_EINVAL, "splits must be 1..65535");
     if ((uint64_t)index_base + n_points > 0xFFFFFFFFull) return fail(RT_DP_EINVAL, "index_base + n_points exceeds the 32-bit index range");
     if ((reinterpret_cast<uintptr_t>(points) | reinterpret_cast<uintptr_t>(queries)) & 7u)
-        return fail(RT_DP_EALIGN, "rt_dp_knn_euclid16: points and queries must be 8-byte aligned");
-    if ((reinterpret_cast<uintptr_t>(out_dist) | reinterpret_cast<uintptr_t>(out_idx)) & 3u)
-        return fail(RT_DP_EALIGN, "rt_dp_knn_euclid16: output arrays must be 4-byte aligned");
+        return fail(RT_DP_EALIGN, "%s: points and queries must be 8-byte aligned", who);
+    if ((reinterpret_cast<uintptr_t>(out_val) | reinterpret_cast<uintptr_t>(out_idx)) & 3u)
+        return fail(RT_DP_EALIGN, "%s: output arrays must be 4-byte aligned", who);
+    if (angular && !ctx->extended) return fail(RT_DP_EINVAL, "%s: the baseline datapath has no angular op", who);
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
-    HIP_TRY(launch_knn_euclid16(points, n_points, queries, n_queries, index_base, splits, out_dist, out_idx,
+    HIP_TRY(launch_knn_euclid16(points, n_points, queries, n_queries, index_base, splits, angular, out_val, out_idx,
                                 hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
     return RT_DP_OK;
+}
+
+}  // namespace
+
+int rt_dp_knn_euclid16(rt_dp_ctx *ctx, const float *points, uint32_t n_points, const float *queries, uint32_t n_queries,
+                       uint32_t index_base, uint32_t splits, float *out_dist, uint32_t *out_idx, void *hip_stream) {
+    return knn_exhaustive(ctx, "rt_dp_knn_euclid16", false, points, n_points, queries, n_queries, index_base, splits, out_dist, out_idx, hip_stream);
+}
+
+int rt_dp_knn_angular16(rt_dp_ctx *ctx, const float *points, uint32_t n_points, const float *queries, uint32_t n_queries,
+                        uint32_t index_base, uint32_t splits, float *out_neg_score, uint32_t *out_idx, void *hip_stream) {
+    return knn_exhaustive(ctx, "rt_dp_knn_angular16", true, points, n_points, queries, n_queries, index_base, splits, out_neg_score, out_idx,
+                          hip_stream);
 }
 
 int rt_dp_knn_tree_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, const float *queries, const uint32_t *home_leaf,

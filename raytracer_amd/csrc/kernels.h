@@ -68,7 +68,7 @@ hipError_t launch_ray_prepare(const RayPrepArgs &args, uint64_t n, hipStream_t s
 // Exact top-16 nearest points per query under the datapath's Euclidean beat (dim 16).
 // out_d / out_i: [splits][n_qry][16], ascending by (distance, index); unused slots hold (+Inf, 0xFFFFFFFF).
 hipError_t launch_knn_euclid16(const float *pts, uint32_t n_pts, const float *qry, uint32_t n_qry, uint32_t idx_base,
-                               uint32_t splits, float *out_d, uint32_t *out_i, hipStream_t stream);
+                               uint32_t splits, bool angular, float *out_d, uint32_t *out_i, hipStream_t stream);
 // fused record-stream path (stream_fused.hip)
 struct StreamSideView {
     const uint32_t *tag;

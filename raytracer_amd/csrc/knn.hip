@@ -47,6 +47,39 @@ __device__ __forceinline__ float knn_pair(const f2v (&qv)[8], const f2v *__restr
     return s[0].x + s[0].y;
 }
 
+// The angular op on a 16-element pair = two 8-element beats through the accumulators (reference
+// src/main/scala/raytracer_datapath/UnifiedDatapath.scala:246-268 masking, :420-453 products, the adder tree
+// (i, i+4), (i, i+2), (0, 1) of :650-676, :804-832, :936-964, accumulators :1028-1064):
+//   dot = (0 + tree(q_i * c_i, i < 8)) + tree(q_i * c_i, i >= 8),  norm likewise over c_i * c_i,
+// followed by what the RTL leaves to its consumer (IOSpec.scala:21-23): score = dot / sqrt(norm), both
+// correctly rounded.  Returned negated, and -0 as +0, so that "larger score first" is the ascending order
+// of the list code; a zero or NaN norm gives NaN, which no compare lets in.
+__device__ __forceinline__ void knn_dot_norm(const f2v (&qv)[8], const f2v *__restrict__ p, float &dot, float &norm) {
+    dot = 0.0f;
+    norm = 0.0f;
+#pragma unroll
+    for (int beat = 0; beat < 2; ++beat) {
+        f2v s[4], m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f2v c = p[beat * 4 + k];
+            s[k] = qv[beat * 4 + k] * c;
+            m[k] = c * c;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { s[k] = s[k] + s[k + 2]; m[k] = m[k] + m[k + 2]; }  // element i with i + 4
+        s[0] = s[0] + s[1];                                                               // i with i + 2
+        m[0] = m[0] + m[1];
+        dot = dot + (s[0].x + s[0].y);
+        norm = norm + (m[0].x + m[0].y);
+    }
+}
+
+__device__ __forceinline__ float knn_neg_score(float dot, float norm) {
+    const float neg = -(dot / sqrtf(norm));
+    return (neg == 0.0f) ? 0.0f : neg;
+}
+
 // One pass of insertion of (cd, ci) into the ascending list; a NaN candidate changes nothing.
 __device__ __forceinline__ void knn_insert(float (&bd)[kTopK], uint32_t (&bi)[kTopK], float cd, uint32_t ci) {
 #pragma unroll
@@ -83,8 +116,22 @@ __device__ __forceinline__ void knn_offer(float (&bd)[kTopK], uint32_t (&bi)[kTo
     }
 }
 
+// The angular search's offer.  The exact key -RN(dot / RN(sqrt(norm))) costs two correctly rounded
+// operations; almost every pair is turned away first by -dot * rsq(norm) (v_rsq_f32, 1 ulp), whose relative
+// distance from the exact key is below 2^-21: a pair is examined exactly when the estimate is within
+// 2^-19 (relative, plus 1e-30 absolute) of the bound, or when norm is so small that the estimate's input may have been flushed.
+// The examined pairs then go through knn_offer with their exact keys, so the lists hold exact keys only.
+__device__ __forceinline__ void knn_offer_angular(float (&bd)[kTopK], uint32_t (&bi)[kTopK], float &pd, uint32_t &pi, float &thr, float dot,
+                                                  float norm, uint32_t idx) {
+    const float est = -(dot * __builtin_amdgcn_rsqf(norm));
+    const float slack = (fabsf(est) + fabsf(thr)) * 1.9073486328125e-06f + 1.0e-30f;  // 2^-19 relative; absolute where the product underflows
+    const bool maybe = (norm < 1.0e-30f) || (est <= thr + slack);
+    if (__any(maybe)) knn_offer(bd, bi, pd, pi, thr, maybe ? knn_neg_score(dot, norm) : __uint_as_float(0x7FC00000u), idx);
+}
+
 constexpr int kKnnUnroll = 4;  // points per loop trip: their scalar loads are issued together
 
+template <bool ANG>
 __global__ __launch_bounds__(256) void k_knn_euclid16(const float *__restrict__ pts, uint32_t n_pts, const float *__restrict__ qry,
                                                      uint32_t n_qry, uint32_t idx_base, uint32_t pts_per_split,
                                                      float *__restrict__ out_d, uint32_t *__restrict__ out_i) {
@@ -108,13 +155,30 @@ __global__ __launch_bounds__(256) void k_knn_euclid16(const float *__restrict__ 
     uint32_t j = j0;
     for (; j + kKnnUnroll <= j1; j += kKnnUnroll) {
         const f2v *p = reinterpret_cast<const f2v *>(pts) + (size_t)j * 8;  // wave-uniform address
-        float dist[kKnnUnroll];
+        if (ANG) {
+            float dot[kKnnUnroll], norm[kKnnUnroll];
 #pragma unroll
-        for (int u = 0; u < kKnnUnroll; ++u) dist[u] = knn_pair(qv, p + u * 8);
+            for (int u = 0; u < kKnnUnroll; ++u) knn_dot_norm(qv, p + u * 8, dot[u], norm[u]);
 #pragma unroll
-        for (int u = 0; u < kKnnUnroll; ++u) knn_offer(bd, bi, pd, pi, thr, dist[u], idx_base + j + u);
+            for (int u = 0; u < kKnnUnroll; ++u) knn_offer_angular(bd, bi, pd, pi, thr, dot[u], norm[u], idx_base + j + u);
+        } else {
+            float dist[kKnnUnroll];
+#pragma unroll
+            for (int u = 0; u < kKnnUnroll; ++u) dist[u] = knn_pair(qv, p + u * 8);
+#pragma unroll
+            for (int u = 0; u < kKnnUnroll; ++u) knn_offer(bd, bi, pd, pi, thr, dist[u], idx_base + j + u);
+        }
     }
-    for (; j < j1; ++j) knn_offer(bd, bi, pd, pi, thr, knn_pair(qv, reinterpret_cast<const f2v *>(pts) + (size_t)j * 8), idx_base + j);
+    for (; j < j1; ++j) {
+        const f2v *p = reinterpret_cast<const f2v *>(pts) + (size_t)j * 8;
+        if (ANG) {
+            float dot, norm;
+            knn_dot_norm(qv, p, dot, norm);
+            knn_offer_angular(bd, bi, pd, pi, thr, dot, norm, idx_base + j);
+        } else {
+            knn_offer(bd, bi, pd, pi, thr, knn_pair(qv, p), idx_base + j);
+        }
+    }
     knn_insert(bd, bi, pd, pi);
     if (live) {
         const size_t o = ((size_t)blockIdx.y * n_qry + q) * kTopK;
@@ -434,11 +498,12 @@ hipError_t launch_knn_retau(uint32_t *tau, const uint32_t *overflow, const float
 }
 
 hipError_t launch_knn_euclid16(const float *pts, uint32_t n_pts, const float *qry, uint32_t n_qry, uint32_t idx_base,
-                               uint32_t splits, float *out_d, uint32_t *out_i, hipStream_t stream) {
+                               uint32_t splits, bool angular, float *out_d, uint32_t *out_i, hipStream_t stream) {
     if (n_qry == 0 || splits == 0) return hipSuccess;
     const uint32_t per = (n_pts + splits - 1) / splits;
     dim3 grid((n_qry + 255) / 256, splits);
-    hipLaunchKernelGGL(k_knn_euclid16, grid, dim3(256), 0, stream, pts, n_pts, qry, n_qry, idx_base, per, out_d, out_i);
+    if (angular) hipLaunchKernelGGL(k_knn_euclid16<true>, grid, dim3(256), 0, stream, pts, n_pts, qry, n_qry, idx_base, per, out_d, out_i);
+    else hipLaunchKernelGGL(k_knn_euclid16<false>, grid, dim3(256), 0, stream, pts, n_pts, qry, n_qry, idx_base, per, out_d, out_i);
     return hipGetLastError();
 }
 

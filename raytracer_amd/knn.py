@@ -30,6 +30,22 @@ def unpack_keys(keys):
     return d, keys & 0xFFFFFFFF
 
 
+def pack_signed_keys(v, i):
+    """Like pack_keys for values of either sign (the angular search's negated scores): the float's bits are mapped to
+    an integer that orders like the float (negative: all bits flipped; non-negative: sign bit set) and shifted into
+    the signed int64 range, so that sorting keys still sorts (value, index).  -0 must not occur (the kernel writes +0)."""
+    b = v.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    u = torch.where(b >= 0x80000000, 0xFFFFFFFF - b, b + 0x80000000)
+    return ((u - 0x80000000) << 32) | (i.to(torch.int64) & 0xFFFFFFFF)
+
+
+def unpack_signed_keys(keys):
+    u = (keys >> 32) + 0x80000000
+    b = torch.where(u >= 0x80000000, u - 0x80000000, 0xFFFFFFFF - u)
+    b = torch.where(b >= 0x80000000, b - (1 << 32), b)
+    return b.to(torch.int32).view(torch.float32), keys & 0xFFFFFFFF
+
+
 def merge_keys(keys, k=TOPK):
     """keys [..., m, n] stacked partial lists -> [m, k] smallest keys per query, ascending."""
     if keys.dim() == 3:
@@ -54,6 +70,25 @@ def local_topk(ctx, points, queries, index_base=0, splits=None, k=TOPK, stream=N
     if s == 0:
         ctx.synchronize()
     return merge_keys(pack_keys(d, i), k)
+
+
+def local_topk_angular(ctx, points, queries, index_base=0, splits=None, k=TOPK, stream=None):
+    """Local top-k of every query by the angular op's score dot / sqrt(norm), largest first, as signed keys [m, k]
+    of (minus score, index); unpack_signed_keys gives the negated scores back."""
+    assert points.shape[1] == 16 and queries.shape[1] == 16 and 1 <= k <= TOPK
+    m = int(queries.shape[0])
+    if splits is None:
+        blocks = (m + 255) // 256
+        splits = max(1, min(64, (2048 + blocks - 1) // blocks, max(1, int(points.shape[0]) // 1024)))
+    v = torch.empty(splits, m, TOPK, dtype=torch.float32, device=queries.device)
+    i = torch.empty(splits, m, TOPK, dtype=torch.int32, device=queries.device)
+    s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+    if s == 0:
+        torch.cuda.current_stream().synchronize()
+    ctx.knn_angular16(points, queries, v, i, index_base=index_base, splits=splits, stream=s)
+    if s == 0:
+        ctx.synchronize()
+    return merge_keys(pack_signed_keys(v, i), k)
 
 
 def all_gather_merge(keys, k=TOPK, group=None):

@@ -73,6 +73,38 @@ def test_knn_sharded_equals_unsharded(ctx, oracle, torch_cuda):
     assert (i.cpu().numpy() == want_i).all() and (d.cpu().numpy().view(np.uint32) == want_d.view(np.uint32)).all()
 
 
+def test_signed_keys_order_like_floats():
+    import torch
+    from raytracer_amd import knn
+    v = torch.tensor([-float("inf"), -3.5, -1e-40, 0.0, 1e-40, 2.0, float("inf")])
+    i = torch.tensor([7, -1, 3, 9, 0, 5, -1], dtype=torch.int32)
+    keys = knn.pack_signed_keys(v, i)
+    assert bool((keys[1:] > keys[:-1]).all())
+    vv, ii = knn.unpack_signed_keys(keys)
+    assert torch.equal(vv.view(torch.int32), v.view(torch.int32)) and ii.tolist() == [7, 0xFFFFFFFF, 3, 9, 0, 5, 0xFFFFFFFF]
+    same = knn.pack_signed_keys(torch.tensor([1.5, 1.5]), torch.tensor([4, 2], dtype=torch.int32))
+    assert same[1] < same[0]  # equal values: the lower index first
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,splits", [(1, 3, 1), (15, 5, 1), (2000, 200, 1), (2000, 200, 5), (5000, 130, None)])
+def test_angular_knn_matches_bruteforce(ctx, oracle, torch_cuda, n, m, splits):
+    torch = torch_cuda
+    from raytracer_amd import knn
+    pts, qry = make_cloud(n, m, seed=3 * n + m)
+    if n >= 64:
+        pts[30] = 0.0                       # zero norm: 0 / 0, never listed
+        pts[31] = pts[32] * f32(2.0)        # same direction as point 32: equal scores up to rounding
+        pts[33] = pts[34]                   # exactly equal scores: the lower index first
+        pts[35] *= f32(1e-25)               # norm underflows towards the subnormal range
+        qry[2] = 0.0                        # every dot product is +-0: all scores tie at 0
+    want_v, want_i = oracle.knn_bruteforce_angular(pts, qry)
+    keys = knn.local_topk_angular(ctx, torch.from_numpy(pts).cuda(), torch.from_numpy(qry).cuda(), 0, splits=splits)
+    v, i = knn.unpack_signed_keys(keys)
+    assert (i.cpu().numpy() == want_i).all()
+    assert (v.cpu().numpy().view(np.uint32) == want_v.view(np.uint32)).all()
+
+
 def clustered_cloud(n, m, seed):
     rng = np.random.default_rng(seed)
     centres = rng.uniform(-1, 1, (12, 16)).astype(f32)
