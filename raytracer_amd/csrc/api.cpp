@@ -675,9 +675,23 @@ int rt_dp_knn_tree_grouped_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, 
     uint32_t *overflow = reinterpret_cast<uint32_t *>(tb + o_ov), *count = reinterpret_cast<uint32_t *>(tb + o_cnt);
     uint32_t *offset = reinterpret_cast<uint32_t *>(tb + o_off), *group_first = reinterpret_cast<uint32_t *>(tb + o_gf);
 
-    // 1. upper bounds: the wave walk over the nearest leaves only; its lists land in the output arrays and are overwritten later
-    HIP_TRY(launch_knn_tree16(view.pts, view.index, view.leaf_lo, view.leaf_hi, nl, ls, queries, home_leaf, n_queries, 0,
-                              walk_leaves ? walk_leaves : 16u, tau, out_dist, out_idx, s));
+    // 1. upper bounds: the wave walk over the nearest leaves only, in up to 8 splits so that a small query set still
+    //    fills the chip; the splits' lists (parked in the candidate buffer) are merged into one bound per query
+    {
+        uint32_t walk = walk_leaves ? walk_leaves : 16u;
+        if (walk > nl) walk = nl;
+        uint32_t lg = 0;
+        while (lg < 3 && (2u << lg) <= nl && (walk >> (lg + 1)) >= 4u && ((nq + 255) / 256 << lg) < 4096) ++lg;
+        const uint32_t sp = 1u << lg;
+        rc = regrow(ctx->d_knn[2], ctx->knn_bytes[2], (size_t)sp * nq * 16 * 8, "k-NN bound lists");
+        if (rc != RT_DP_OK) return rc;
+        float *bd = reinterpret_cast<float *>(ctx->d_knn[2]);
+        uint32_t *bi = reinterpret_cast<uint32_t *>(ctx->d_knn[2] + (size_t)sp * nq * 16 * 4);
+        HIP_TRY(launch_knn_tree16(view.pts, view.index, view.leaf_lo, view.leaf_hi, nl, ls, queries, home_leaf, n_queries, lg,
+                                  (walk + sp - 1) / sp, tau, bd, bi, s));
+        HIP_TRY(launch_knn_tau_merge(bd, sp, n_queries, tau, s));
+        HIP_TRY(hipStreamSynchronize(s));  // the candidate buffer is re-used (and possibly re-allocated) below
+    }
     // Rounds of: per-leaf query lists (count, prefix sums on the host, fill), scan, select.  Queries that fill
     // their candidate slots go into another round with a tighter bound; everything else is settled.
     uint64_t cap = 1024, pairs_total = 0, groups_total = 0, rounds = 0;

@@ -110,6 +110,7 @@ hipError_t launch_knn_leaf_scan(const KnnTreeView &t, const float *qry, const ui
                                 uint32_t cap, uint32_t *n_cand, unsigned long long *cand, hipStream_t stream);
 hipError_t launch_knn_select(const uint32_t *tau, const uint32_t *n_cand, const unsigned long long *cand, uint32_t cap, uint32_t n_qry,
                              float *out_d, uint32_t *out_i, uint32_t *overflow, hipStream_t stream);
+hipError_t launch_knn_tau_merge(const float *lists, uint32_t splits, uint32_t n_qry, uint32_t *tau, hipStream_t stream);
 hipError_t launch_knn_retau(uint32_t *tau, const uint32_t *overflow, const float *out_d, uint32_t n_qry, uint32_t *status, hipStream_t stream);
 
 }  // namespace rtdp

@@ -485,6 +485,36 @@ __global__ __launch_bounds__(256) void k_knn_retau(uint32_t *__restrict__ tau, c
     else tau[q] = t;
 }
 
+// The bound phase runs the wave walk in several splits for parallelism; each split's list holds the 16 best of
+// its own leaves.  The 16th smallest distance over all splits' lists is the bound the union supports.
+__global__ __launch_bounds__(256) void k_knn_tau_merge(const float *__restrict__ lists, uint32_t splits, uint32_t n_qry,
+                                                      uint32_t *__restrict__ tau) {
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= n_qry) return;
+    float best[kTopK];
+#pragma unroll
+    for (int t = 0; t < kTopK; ++t) best[t] = lists[(size_t)q * kTopK + t];  // split 0, ascending
+    for (uint32_t sp = 1; sp < splits; ++sp) {
+        for (int t = 0; t < kTopK; ++t) {
+            float c = lists[((size_t)sp * n_qry + q) * kTopK + t];
+            if (!(c < best[kTopK - 1])) break;  // ascending: nothing further in this list can enter
+#pragma unroll
+            for (int u = 0; u < kTopK; ++u) {
+                const bool lt = c < best[u];
+                const float keep = lt ? c : best[u];
+                c = lt ? best[u] : c;
+                best[u] = keep;
+            }
+        }
+    }
+    tau[q] = __float_as_uint(best[kTopK - 1]);
+}
+
+hipError_t launch_knn_tau_merge(const float *lists, uint32_t splits, uint32_t n_qry, uint32_t *tau, hipStream_t stream) {
+    hipLaunchKernelGGL(k_knn_tau_merge, dim3((n_qry + 255) / 256), dim3(256), 0, stream, lists, splits, n_qry, tau);
+    return hipGetLastError();
+}
+
 hipError_t launch_knn_select(const uint32_t *tau, const uint32_t *n_cand, const unsigned long long *cand, uint32_t cap, uint32_t n_qry,
                              float *out_d, uint32_t *out_i, uint32_t *overflow, hipStream_t stream) {
     if (n_qry == 0) return hipSuccess;
