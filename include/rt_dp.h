@@ -305,7 +305,7 @@ int rt_dp_knn_angular16(rt_dp_ctx *ctx, const float *points, uint32_t n_points, 
  *                                        which a point of the leaf is NaN must be (-Inf, +Inf)
  * (raytracer_amd/knn_tree.py builds this from a point set with a median-split k-d tree).
  * queries [n_queries][16]; home_leaf[n_queries] names, per query, the leaf from which its walk
- * starts (any leaf is valid; the leaf the query falls into prunes best, and queries should be
+ * starts (any value is accepted and reduced modulo n_leaves; the leaf the query falls into prunes best, and queries should be
  * sorted by it, because 64 consecutive queries walk together).  `splits` (a power of two,
  * <= n_leaves) spreads the leaves of one query over that many workgroups; bound[n_queries]
  * is scratch the call initialises.  out_dist / out_idx are [splits][n_queries][16] as for

@@ -237,7 +237,9 @@ __global__ __launch_bounds__(256) void k_knn_tree16(KnnTreeArgs tree, const floa
 
     const uint32_t split = blockIdx.y;
     const uint32_t per_split = tree.n_leaves >> tree.log2_splits;
-    const uint32_t hh = __builtin_amdgcn_readfirstlane(home[qq]) >> tree.log2_splits;  // the wave follows its first query
+    // the wave follows its first query; the value is reduced into the leaf range, so no caller-supplied number can
+    // steer the walk outside the index
+    const uint32_t hh = (__builtin_amdgcn_readfirstlane(home[qq]) >> tree.log2_splits) & (per_split - 1u);
     const f2v *pts2 = reinterpret_cast<const f2v *>(tree.pts);
 
     const uint32_t n_walk = (tree.walk && tree.walk < per_split) ? tree.walk : per_split;

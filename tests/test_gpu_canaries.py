@@ -1,0 +1,139 @@
+"""No entry point may write outside the arrays it was given: every output lives between two guard zones filled
+with a sentinel, for sizes around the kernels' wave / workgroup / tile granularities, each on a fresh context."""
+import numpy as np
+import pytest
+
+from raytracer_amd import bvh, capi, gen
+
+pytestmark = pytest.mark.gpu
+GUARD = 4096            # words on either side
+SENT = 0x5A5A5A5A
+
+
+class Guarded:
+    """Device tensors carved out of guarded pools."""
+
+    def __init__(self, torch):
+        self.torch, self.pools = torch, []
+
+    def empty(self, shape, dtype):
+        torch = self.torch
+        n = int(np.prod(shape))
+        n4 = (n + 3) // 4 * 4   # keep 16-byte alignment of the payload
+        pool = torch.full((GUARD + n4 + GUARD,), SENT, dtype=torch.int32, device="cuda")
+        self.pools.append((pool, n))
+        return pool[GUARD:GUARD + n].view(dtype).view(*shape)
+
+    def check(self):
+        for pool, n in self.pools:
+            lo, hi = pool[:GUARD], pool[GUARD + n:]
+            assert bool((lo == SENT).all()) and bool((hi == SENT).all()), "a kernel wrote outside an output array of %d words" % n
+
+
+SIZES = [1, 2, 63, 64, 65, 127, 255, 256, 257, 511, 513, 1000, 1025, 2049, 4099]
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_op_batches_stay_inside_their_outputs(torch_cuda, n):
+    torch = torch_cuda
+    g = Guarded(torch)
+    c = capi.Context()
+    f32, i32 = torch.float32, torch.int32
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    b = capi.Batch()
+    b.set_box([dev(f) for f in gen.box_ops(n, seed=n)], [g.empty((n,), f32) for _ in range(4)], g.empty((n,), i32), n)
+    tf, tk = gen.tri_ops(n, seed=n + 1)
+    b.set_tri([dev(f) for f in tf], dev(tk.view(np.int32)), g.empty((n,), f32), g.empty((n,), f32), g.empty((n,), i32), n)
+    a, bb, ctl, _ = gen.vec_beats(max(1, n // 5), 16, seed=n + 2)
+    b.set_euclid(dev(a), dev(bb), dev(ctl.view(np.int32)), g.empty((ctl.shape[0],), f32))
+    q, cc, ctl8, _ = gen.vec_beats(max(1, n // 5), 8, seed=n + 3)
+    b.set_angular(dev(q), dev(cc), dev(ctl8.view(np.int32)), g.empty((ctl8.shape[0],), f32), g.empty((ctl8.shape[0],), f32))
+    torch.cuda.synchronize()
+    c.eval(b)
+    torch.cuda.synchronize()
+    g.check()
+    c.close()
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("mode", [1, 2])
+def test_record_streams_stay_inside_their_output(torch_cuda, n, mode):
+    torch = torch_cuda
+    g = Guarded(torch)
+    c = capi.Context()
+    c.set_option("stream_mode", mode)
+    rng = np.random.default_rng(n)
+    rec = rng.integers(0, 1 << 32, (n, 84), dtype=np.uint64).astype(np.uint32)
+    rec[:, 0] = rng.integers(0, 4, n)
+    rec[:, 11:14] &= 3
+    out = g.empty((n, 21), torch.int32)
+    c.eval_bundles_device(torch.from_numpy(rec.view(np.int32)).cuda(), out)
+    torch.cuda.synchronize()
+    g.check()
+    c.close()
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (5, 3), (63, 65), (300, 257), (1000, 64), (4099, 700)])
+def test_searches_stay_inside_their_outputs(torch_cuda, n, m):
+    torch = torch_cuda
+    from raytracer_amd import knn_tree
+    g = Guarded(torch)
+    c = capi.Context()
+    gen_t = torch.Generator(device="cuda").manual_seed(n * 1000 + m)
+    P = torch.rand(n, 16, generator=gen_t, device="cuda") * 2 - 1
+    Q = torch.rand(m, 16, generator=gen_t, device="cuda") * 2 - 1
+    f32, i32 = torch.float32, torch.int32
+    sync = torch.cuda.synchronize   # the library's stream is not ordered behind torch's: finish torch's work before each call
+    for splits in (1, 3):
+        outs = [g.empty((splits, m, 16), f32), g.empty((splits, m, 16), i32), g.empty((splits, m, 16), f32), g.empty((splits, m, 16), i32)]
+        sync()
+        c.knn_euclid16(P, Q, outs[0], outs[1], splits=splits)
+        c.knn_angular16(P, Q, outs[2], outs[3], splits=splits)
+    for leaf in (4, 64):
+        tree = knn_tree.KnnTree(P, leaf_size=leaf)
+        home = tree.home_leaf(Q)
+        order = home.argsort(stable=True)
+        qs, hs = Q[order].contiguous(), home[order].contiguous()
+        for splits in (1, 2):
+            if splits <= tree.n_leaves:
+                outs = [g.empty((m,), i32), g.empty((splits, m, 16), f32), g.empty((splits, m, 16), i32)]
+                sync()
+                c.knn_tree_euclid16(tree, qs, hs, outs[0], outs[1], outs[2], splits=splits)
+        outs = [g.empty((m, 16), f32), g.empty((m, 16), i32)]
+        sync()
+        c.knn_tree_grouped_euclid16(tree, qs, hs, outs[0], outs[1], walk_leaves=8)
+        wild = torch.full((m,), 0x7FFFFFF1, dtype=i32, device="cuda")   # a nonsensical home leaf must not steer the walk outside the index
+        outs = [g.empty((m,), i32), g.empty((1, m, 16), f32), g.empty((1, m, 16), i32)]
+        sync()
+        c.knn_tree_euclid16(tree, qs, wild, outs[0], outs[1], outs[2], splits=1)
+    c.synchronize()
+    torch.cuda.synchronize()
+    g.check()
+    c.close()
+
+
+@pytest.mark.parametrize("n_tris,n_rays", [(1, 1), (7, 63), (100, 65), (900, 257), (3000, 1025)])
+@pytest.mark.parametrize("wavefront", [False, True])
+def test_traversal_and_ray_prepare_stay_inside_their_outputs(torch_cuda, n_tris, n_rays, wavefront):
+    torch = torch_cuda
+    g = Guarded(torch)
+    c = capi.Context()
+    tris = bvh.random_scene(n_tris, seed=n_tris)
+    nodes, tris12, _ = bvh.build_bvh4(tris)
+    org, dirs = bvh.rays_towards(tris, n_rays, seed=n_rays)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    o = [dev(org[:, a]) for a in range(3)]
+    d = [dev(dirs[:, a]) for a in range(3)]
+    out_t, out_i = g.empty((n_rays,), torch.float32), g.empty((n_rays,), torch.int32)
+    N, T = dev(nodes), dev(tris12)
+    torch.cuda.synchronize()
+    c.trace_closest(N, T, o, d, 4000.0, out_t, out_i, wavefront=wavefront)
+    f32 = torch.float32
+    inv, k = [g.empty((n_rays,), f32) for _ in range(3)], g.empty((n_rays,), torch.int32)
+    shear, extent = [g.empty((n_rays,), f32) for _ in range(3)], g.empty((n_rays,), f32)
+    torch.cuda.synchronize()
+    c.ray_prepare(d, inv=inv, k=k, shear=shear, extent=extent)
+    c.synchronize()
+    torch.cuda.synchronize()
+    g.check()
+    c.close()
