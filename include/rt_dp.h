@@ -189,7 +189,11 @@ int rt_dp_eval_ctx(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch 
  * RT_DP_F_DEVICE_PTRS, enqueues the kernels on `hip_stream` (a hipStream_t;
  * NULL = the context's own non-blocking stream) and returns without
  * synchronising.  Ordering against the producers of the operands is the
- * caller's: launch on the stream that produced them, or synchronise first.    */
+ * caller's: launch on the stream that produced them, or synchronise first.
+ * The same holds for every entry point below that is described as
+ * asynchronous (rt_dp_ray_prepare, rt_dp_knn_euclid16, rt_dp_knn_angular16,
+ * rt_dp_knn_tree_euclid16); the synchronous ones wait for the whole device
+ * before they read their arguments.                                            */
 int rt_dp_launch(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *out, void *hip_stream);
 int rt_dp_synchronize(rt_dp_ctx *ctx);
 
