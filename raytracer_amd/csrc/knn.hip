@@ -1,4 +1,9 @@
-// Exact k-nearest-neighbour search on the datapath's Euclidean distance op.
+// Exact k-nearest-neighbour search on the datapath's distance ops.  In this file:
+//   k_knn_euclid16<false>  exhaustive scan ranked by the Euclidean op
+//   k_knn_euclid16<true>   exhaustive scan ranked by the angular op's dot / sqrt(norm)
+//   k_knn_tree16           the Euclidean search through a k-d index, wave by wave with box pruning
+//   k_knn_pairs, k_knn_leaf_scan, k_knn_select, ...   the same search leaf by leaf
+// All of them return the same lists for the same points.
 //
 // The distance between a query and a point (both 16 f32 = one beat) is exactly what
 // the RTL delivers for a single-beat vector pair with mask 0xFFFF and reset 1:
@@ -14,7 +19,7 @@
 // registers); the point index is wave-uniform, so the point's coordinates come in
 // through the scalar data path (s_load) and feed the VALU as SGPR operands: no LDS,
 // no barrier.  blockIdx.y splits the points so that a small query set still fills
-// the chip; partial lists are merged afterwards (merge_topk in raytracer_amd/knn.py,
+// the chip; partial lists are merged afterwards (merge_keys in raytracer_amd/knn.py,
 // the same merge that combines the per-GPU lists after the RCCL all-gather).
 #include "kernels.h"
 
