@@ -97,6 +97,12 @@ def all_gather_merge(keys, k=TOPK, group=None):
         return keys
     world = dist.get_world_size(group)
     m, kk = keys.shape
+    if keys.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal of the exchange without RCCL (e.g. several ranks on one GPU): gloo moves host memory
+        host = keys.contiguous().cpu()
+        gathered = torch.empty((world * m, kk), dtype=keys.dtype)
+        dist.all_gather_into_tensor(gathered, host, group=group)
+        return merge_keys(gathered.to(keys.device).view(world, m, kk), k)
     gathered = torch.empty((world * m, kk), dtype=keys.dtype, device=keys.device)  # rank-major concatenation
     dist.all_gather_into_tensor(gathered, keys.contiguous(), group=group)
     return merge_keys(gathered.view(world, m, kk), k)
