@@ -54,6 +54,9 @@ struct rt_dp_ctx {
     // grow-only workspace of the device-side record stream path (slots, block offsets)
     char *d_stream = nullptr;
     size_t stream_bytes = 0;
+    // staging of host-resident record streams (input records, then output records)
+    char *d_records = nullptr;
+    size_t records_bytes = 0;
     // traversal driver: ray records + best[] + counters in d_trace, three work queues
     char *d_trace = nullptr;
     size_t trace_bytes = 0;
@@ -329,6 +332,7 @@ void rt_dp_destroy(rt_dp_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_stream) (void)hipFree(ctx->d_stream);
+    if (ctx->d_records) (void)hipFree(ctx->d_records);
     if (ctx->d_trace) (void)hipFree(ctx->d_trace);
     for (char *q : ctx->d_queue)
         if (q) (void)hipFree(q);
@@ -902,101 +906,26 @@ int rt_dp_eval_bundles(rt_dp_ctx *ctx, const rt_dp_input_bundle *in, rt_dp_outpu
     if (n == 0) return RT_DP_OK;
     if (!in || !out) return fail(RT_DP_ENULL, "rt_dp_eval_bundles: in/out is NULL");
     if (n > kMaxOps) return fail(RT_DP_EINVAL, "n = %llu is not representable (limit 2^40)", (unsigned long long)n);
-
-    std::vector<uint64_t> idx[4];
-    for (uint64_t i = 0; i < n; ++i) {
-        if (in[i].opcode > 3u) return fail(RT_DP_EOPCODE, "record %llu has opcode %u; the RTL's opcode field is 2 bits wide", (unsigned long long)i, in[i].opcode);
-        idx[in[i].opcode].push_back(i);
-    }
-    const uint64_t nt = idx[0].size(), nb = idx[1].size(), ne = idx[2].size(), na = idx[3].size();
-    auto F = [](uint32_t bits) { float f; memcpy(&f, &bits, 4); return f; };
-    auto B = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
-
-    // SoA images
-    std::vector<float> tri_in[kTriFields], box_in[kBoxFields], box_t[4], tri_num(nt), tri_den(nt);
-    std::vector<uint32_t> tri_k(nt), tri_hit(nt), box_flags(nb), euc_ctl(ne), ang_ctl(na);
-    std::vector<float> euc_a(ne * 16), euc_b(ne * 16), euc_o(ne), ang_a(na * 8), ang_b(na * 8), ang_d(na), ang_n(na);
-    for (auto &v : tri_in) v.resize(nt);
-    for (auto &v : box_in) v.resize(nb);
-    for (auto &v : box_t) v.resize(nb);
-
-    for (uint64_t j = 0; j < nt; ++j) {
-        const rt_dp_input_bundle &r = in[idx[0][j]];
-        const uint32_t w[kTriFields] = {r.ray.origin.x, r.ray.origin.y, r.ray.origin.z, r.ray.shear.x, r.ray.shear.y, r.ray.shear.z,
-                                        r.triangle.A.x, r.triangle.A.y, r.triangle.A.z, r.triangle.B.x, r.triangle.B.y, r.triangle.B.z,
-                                        r.triangle.C.x, r.triangle.C.y, r.triangle.C.z};
-        for (int f = 0; f < kTriFields; ++f) tri_in[f][j] = F(w[f]);
-        tri_k[j] = (r.ray.kx & 3u) | ((r.ray.ky & 3u) << 2) | ((r.ray.kz & 3u) << 4);
-    }
-    for (uint64_t j = 0; j < nb; ++j) {
-        const rt_dp_input_bundle &r = in[idx[1][j]];
-        uint32_t w[kBoxFields] = {r.ray.origin.x, r.ray.origin.y, r.ray.origin.z, r.ray.dir.x, r.ray.dir.y, r.ray.dir.z,
-                                  r.ray.inv.x, r.ray.inv.y, r.ray.inv.z, r.ray.extent};
-        for (int b = 0; b < 4; ++b) {
-            const rt_dp_aabb &bb = r.aabb[b];
-            const uint32_t q[6] = {bb.x_min, bb.y_min, bb.z_min, bb.x_max, bb.y_max, bb.z_max};
-            for (int f = 0; f < 6; ++f) w[10 + 6 * b + f] = q[f];
-        }
-        for (int f = 0; f < kBoxFields; ++f) box_in[f][j] = F(w[f]);
-    }
-    for (uint64_t j = 0; j < ne; ++j) {
-        const rt_dp_input_bundle &r = in[idx[2][j]];
-        for (int e = 0; e < 16; ++e) { euc_a[j * 16 + e] = F(r.euclidean_a[e]); euc_b[j * 16 + e] = F(r.euclidean_b[e]); }
-        euc_ctl[j] = RT_DP_CTL(r.euclidean_mask & 0xFFFFu, r.euclidean_reset_accum & 1u);
-    }
-    for (uint64_t j = 0; j < na; ++j) {
-        const rt_dp_input_bundle &r = in[idx[3][j]];
-        for (int e = 0; e < 8; ++e) { ang_a[j * 8 + e] = F(r.euclidean_a[e]); ang_b[j * 8 + e] = F(r.euclidean_b[e]); }
-        ang_ctl[j] = RT_DP_CTL(r.euclidean_mask & 0xFFFFu, r.euclidean_reset_accum & 1u);
-    }
-
-    rt_dp_op_batch ob;
-    rt_dp_result_batch rb;
-    memset(&ob, 0, sizeof ob);
-    memset(&rb, 0, sizeof rb);
-    ob.struct_size = sizeof ob;
-    rb.struct_size = sizeof rb;
-    ob.n[0] = nt; ob.n[1] = nb; ob.n[2] = ne; ob.n[3] = na;
-    for (int a = 0; a < 3; ++a) { ob.tri.org[a] = tri_in[a].data(); ob.tri.shear[a] = tri_in[3 + a].data(); }
-    for (int v = 0; v < 3; ++v)
-        for (int a = 0; a < 3; ++a) ob.tri.vtx[v][a] = tri_in[6 + 3 * v + a].data();
-    ob.tri.k = tri_k.data();
-    rb.tri.t_num = tri_num.data(); rb.tri.t_denom = tri_den.data(); rb.tri.hit = tri_hit.data();
-    for (int a = 0; a < 3; ++a) { ob.box.org[a] = box_in[a].data(); ob.box.dir[a] = box_in[3 + a].data(); ob.box.inv[a] = box_in[6 + a].data(); }
-    ob.box.extent = box_in[9].data();
-    for (int b = 0; b < 4; ++b)
-        for (int f = 0; f < 6; ++f) ob.box.aabb[b][f] = box_in[10 + 6 * b + f].data();
-    for (int k = 0; k < 4; ++k) rb.box.tmin_out[k] = box_t[k].data();
-    rb.box.flags = box_flags.data();
-    ob.euc.a = euc_a.data(); ob.euc.b = euc_b.data(); ob.euc.ctl = euc_ctl.data(); rb.euc.accumulator = euc_o.data();
-    ob.ang.a = ang_a.data(); ob.ang.b = ang_b.data(); ob.ang.ctl = ang_ctl.data(); rb.ang.dot_product = ang_d.data(); rb.ang.norm = ang_n.data();
-
-    int rc = rt_dp_eval_ctx(ctx, &ob, &rb);
+    for (uint64_t i = 0; i < n; ++i)
+        if (in[i].opcode > 3u)
+            return fail(RT_DP_EOPCODE, "record %llu has opcode %u; the RTL's opcode field is 2 bits wide", (unsigned long long)i, in[i].opcode);
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
+    // host records: staged through device memory in pieces and evaluated by the device-resident path
+    // (stable per opcode, so the accumulators run on from piece to piece like from call to call)
+    const uint64_t piece = 1ull << 22;
+    const uint64_t cap = n < piece ? n : piece;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    int rc = regrow(ctx->d_records, ctx->records_bytes, cap * (sizeof(rt_dp_input_bundle) + sizeof(rt_dp_output_bundle)), "record staging");
     if (rc != RT_DP_OK) return rc;
-
-    for (uint64_t i = 0; i < n; ++i) {
-        memset(&out[i], 0, sizeof out[i]);
-        out[i].opcode = in[i].opcode;
-        if (ctx->extended) {
-            out[i].euclidean_reset_accum = in[i].euclidean_reset_accum & 1u;
-            out[i].angular_reset_accum = in[i].euclidean_reset_accum & 1u;
-        }
-    }
-    for (uint64_t j = 0; j < nt; ++j) {
-        rt_dp_output_bundle &o = out[idx[0][j]];
-        o.t_num = B(tri_num[j]); o.t_denom = B(tri_den[j]); o.triangle_hit = tri_hit[j];
-    }
-    for (uint64_t j = 0; j < nb; ++j) {
-        rt_dp_output_bundle &o = out[idx[1][j]];
-        for (int k = 0; k < 4; ++k) {
-            o.tmin_out[k] = B(box_t[k][j]);
-            o.isIntersect[k] = RT_DP_BOX_ISECT(box_flags[j], k);
-            o.boxIndex[k] = RT_DP_BOX_INDEX(box_flags[j], k);
-        }
-    }
-    if (ctx->extended) {
-        for (uint64_t j = 0; j < ne; ++j) out[idx[2][j]].euclidean_accumulator = B(euc_o[j]);
-        for (uint64_t j = 0; j < na; ++j) { out[idx[3][j]].angular_dot_product = B(ang_d[j]); out[idx[3][j]].angular_norm = B(ang_n[j]); }
+    rt_dp_input_bundle *d_in = reinterpret_cast<rt_dp_input_bundle *>(ctx->d_records);
+    rt_dp_output_bundle *d_out = reinterpret_cast<rt_dp_output_bundle *>(ctx->d_records + cap * sizeof(rt_dp_input_bundle));
+    for (uint64_t off = 0; off < n; off += piece) {
+        const uint64_t m = (n - off < piece) ? (n - off) : piece;
+        HIP_TRY(hipMemcpy(d_in, in + off, m * sizeof(rt_dp_input_bundle), hipMemcpyHostToDevice));
+        rc = rt_dp_eval_bundles_device(ctx, d_in, d_out, m);
+        if (rc != RT_DP_OK) return rc;
+        HIP_TRY(hipMemcpy(out + off, d_out, m * sizeof(rt_dp_output_bundle), hipMemcpyDeviceToHost));
     }
     return RT_DP_OK;
 }
