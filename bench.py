@@ -13,6 +13,14 @@ One JSON line is printed by rank 0.  Besides the contract fields it carries
   roofline      -- the dominant kernel against the HBM roof (algorithmic bytes)
   cpu_baseline  -- the scalar C golden model (oracle B) timed on the host cores
   per_opcode    -- the other three opcodes and a mixed batch, each with a roofline
+
+Other workloads, one JSON line each:
+  --only tri|euclid|angular|mixed     one opcode (or the mixed batch) as the headline
+  --only stream [--stream-mode 1|2]   record-at-a-time streams resident in HBM
+  --only knn [--knn-tree 0|1|2] [--knn-metric angular] [--knn-data clustered]
+                                      exact top-16 search, 2^20 points x 2^16 queries (strong scaling over GPUs)
+  --only trace [--trace-wavefront 1]  closest-hit traversal of a 4-wide hierarchy
+  --sweep                             A/B of the kernel shapes
 """
 import argparse
 import json
