@@ -64,6 +64,17 @@ def test_argument_errors_without_a_device():
     assert L.rt_dp_launch(None, None, None, None) == capi.ENULL
     assert L.rt_dp_eval_bundles(None, None, None, 1) == capi.ENULL
     assert L.rt_dp_get_accum(None, None) == capi.ENULL
+    # the search / traversal / stream entry points refuse a NULL context before touching anything else
+    assert L.rt_dp_eval_bundles_device(None, None, None, 1) == capi.ENULL
+    assert L.rt_dp_ray_prepare(None, None, 1, None) == capi.ENULL
+    assert L.rt_dp_knn_euclid16(None, None, 1, None, 1, 0, 1, None, None, None) == capi.ENULL
+    assert L.rt_dp_knn_angular16(None, None, 1, None, 1, 0, 1, None, None, None) == capi.ENULL
+    assert L.rt_dp_knn_tree_euclid16(None, None, None, None, 1, 1, None, None, None, None) == capi.ENULL
+    assert L.rt_dp_knn_tree_grouped_euclid16(None, None, None, None, 1, 16, None, None, None) == capi.ENULL
+    assert L.rt_dp_trace_closest(None, None, None, None, 1, 4000.0, 0, None, None, None) == capi.ENULL
+    assert L.rt_dp_set_option(None, b"variant", 0) == capi.ENULL
+    assert L.rt_dp_set_tuning(None, 0, 0, 0) == capi.ENULL
+    assert L.rt_dp_synchronize(None) == capi.ENULL
     L.rt_dp_destroy(None)  # a no-op
 
 
