@@ -170,6 +170,36 @@ def test_tree_argument_errors(ctx, torch_cuda):
         ctx.knn_tree_euclid16(tree, Q, h, b, d[:1].contiguous(), i[:1].contiguous(), splits=1)
 
 
+@pytest.mark.gpu
+def test_search_argument_errors(ctx, torch_cuda):
+    torch = torch_cuda
+    from raytracer_amd import capi, knn_tree
+    P = torch.rand(257, 16, device="cuda")
+    Q = torch.rand(10, 16, device="cuda")
+    d = torch.empty(1, 10, 16, device="cuda")
+    i = torch.empty(1, 10, 16, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    L, h = capi.load(), ctx._h
+    args = lambda p, q: (h, p, 256, q, 10, 0, 1, d.data_ptr(), i.data_ptr(), None)
+    assert L.rt_dp_knn_euclid16(*args(P.data_ptr(), Q.data_ptr())) == capi.OK
+    assert L.rt_dp_knn_euclid16(*args(P.data_ptr() + 4, Q.data_ptr())) == capi.EALIGN      # 8-byte alignment of the coordinates
+    assert L.rt_dp_knn_angular16(*args(P.data_ptr(), Q.data_ptr() + 4)) == capi.EALIGN
+    assert L.rt_dp_knn_euclid16(h, P.data_ptr(), 256, Q.data_ptr(), 10, 0, 0, d.data_ptr(), i.data_ptr(), None) == capi.EINVAL   # splits = 0
+    assert L.rt_dp_knn_euclid16(h, P.data_ptr(), 256, Q.data_ptr(), 10, 0xFFFFFFF0, 1, d.data_ptr(), i.data_ptr(), None) == capi.EINVAL  # index overflow
+    assert L.rt_dp_knn_euclid16(h, P.data_ptr(), 256, None, 10, 0, 1, d.data_ptr(), i.data_ptr(), None) == capi.ENULL
+    base = capi.Context(support_euclidean=0)
+    assert L.rt_dp_knn_angular16(base._h, P.data_ptr(), 256, Q.data_ptr(), 10, 0, 1, d.data_ptr(), i.data_ptr(), None) == capi.EINVAL  # no angular op
+    base.close()
+    tree = knn_tree.KnnTree(P, leaf_size=64)
+    hs = torch.zeros(10, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    tree.n_leaves = 3
+    with pytest.raises(capi.RtDpError) as e:
+        ctx.knn_tree_grouped_euclid16(tree, Q, hs, d[0], i[0])
+    assert e.value.code == capi.EINVAL
+    ctx.synchronize()
+
+
 def test_tree_build_is_a_balanced_partition():
     import torch
     from raytracer_amd import knn_tree

@@ -111,3 +111,35 @@ def test_trace_rejects_a_broken_hierarchy(ctx, torch_cuda):
     bad[0, 25:26] = np.array([bvh.leaf_ref(98, 4)], u32).view(f32)   # a leaf running past the triangle array
     with pytest.raises(capi.RtDpError):
         run_gpu(ctx, torch, bad, tris12, org, dirs, 4000.0)
+
+
+@pytest.mark.gpu
+def test_trace_argument_errors(ctx, torch_cuda):
+    torch = torch_cuda
+    import ctypes as C
+    from raytracer_amd import capi
+    tris = bvh.random_scene(50, seed=8)
+    nodes, tris12, _ = bvh.build_bvh4(tris)
+    org, dirs = bvh.rays_towards(tris, 16)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    N, T = dev(nodes), dev(tris12)
+    o = [dev(org[:, a]) for a in range(3)]
+    d = [dev(dirs[:, a]) for a in range(3)]
+    t = torch.empty(16, dtype=torch.float32, device="cuda")
+    i = torch.empty(16, dtype=torch.int32, device="cuda")
+    L = capi.load()
+    b = capi.Bvh4(C.sizeof(capi.Bvh4), nodes.shape[0], tris12.shape[0], 0, N.data_ptr(), T.data_ptr())
+    op = (C.c_void_p * 3)(*[x.data_ptr() for x in o])
+    dp = (C.c_void_p * 3)(*[x.data_ptr() for x in d])
+    call = lambda bv, flags, org_ptrs=op: L.rt_dp_trace_closest(ctx._h, C.byref(bv), C.byref(org_ptrs), C.byref(dp), 16, 4000.0, flags,
+                                                                 t.data_ptr(), i.data_ptr(), None)
+    assert call(b, 0) == capi.OK and call(b, capi.TRACE_WAVEFRONT) == capi.OK
+    assert call(b, 2) == capi.EINVAL                                   # unknown flag
+    odd = (C.c_void_p * 3)(o[0].data_ptr() + 4, o[1].data_ptr(), o[2].data_ptr())
+    assert call(b, 0, odd) == capi.EALIGN                              # 16-byte alignment of the ray arrays
+    none = (C.c_void_p * 3)(None, o[1].data_ptr(), o[2].data_ptr())
+    assert call(b, 0, none) == capi.ENULL
+    empty = capi.Bvh4(C.sizeof(capi.Bvh4), 0, tris12.shape[0], 0, N.data_ptr(), T.data_ptr())
+    assert call(empty, 0) == capi.EINVAL                               # no root
+    wrong = capi.Bvh4(8, nodes.shape[0], tris12.shape[0], 0, N.data_ptr(), T.data_ptr())
+    assert call(wrong, 0) == capi.EINVAL                               # struct_size
