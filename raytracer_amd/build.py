@@ -58,6 +58,13 @@ def build(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+    ex_src, ex = os.path.join(ROOT, "examples", "kat_from_c.c"), os.path.join(LIBDIR, "kat_from_c")
+    if os.path.exists(ex_src) and (force or _stale(ex, [ex_src, LIB, os.path.join(ROOT, "include", "rt_dp.h")])):
+        cmd = ["gcc", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), ex_src, "-o", ex, "-L", LIBDIR, "-lrt_dp", "-lm",
+               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]  # plain C: the header and the ABI without any C++
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     mb_src, mb = os.path.join(CSRC, "membench.hip"), os.path.join(LIBDIR, "membench")
     if os.path.exists(mb_src) and (force or _stale(mb, [mb_src])):
         cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", mb_src, "-o", mb]

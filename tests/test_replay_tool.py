@@ -42,3 +42,22 @@ def test_replay_reports_a_corrupted_expectation(tmp_path):
     bad.write_text("\n".join(lines) + "\n")
     r = subprocess.run([TOOL, str(bad)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "1 mismatching" in r.stdout
+
+
+KAT = os.path.join(ROOT, "raytracer_amd", "lib", "kat_from_c")
+
+
+def test_c_example_is_built_and_reports_a_missing_gpu():
+    import torch
+    assert os.path.exists(KAT), "build it with python -m raytracer_amd.build"
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([KAT], capture_output=True, text=True)
+    assert r.returncode == 2 and "no HIP device" in r.stdout  # rt_dp_eval fails loudly, nothing is computed on the CPU
+
+
+@pytest.mark.gpu
+def test_known_answers_from_plain_c():
+    """examples/kat_from_c.c: the four hand-derived known-answer cases through rt_dp_eval, host arrays, C only."""
+    r = subprocess.run([KAT], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "KAT OK" in r.stdout, r.stdout + r.stderr
