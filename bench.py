@@ -63,6 +63,7 @@ def parse():
     p.add_argument("--knn-log2-queries", type=int, default=16)
     p.add_argument("--stream-mode", type=int, default=0, help="record streams: 0 automatic, 1 partition by opcode first, 2 fused single pass")
     p.add_argument("--trace-wavefront", type=int, default=0, help="1: breadth-first walk with queue compaction; 0: depth-first walk")
+    p.add_argument("--trace-sorted", type=int, default=0, help="1: rays sorted by origin / target cell (coherent waves)")
     p.add_argument("--trace-log2-tris", type=int, default=18)
     p.add_argument("--trace-log2-rays", type=int, default=22)
     p.add_argument("--knn-tree", type=int, default=2, help="1: walk the k-d tree index with box pruning; 2: leaf-major search on the same index; 0: exhaustive scan")
@@ -336,6 +337,12 @@ def run_trace(a, world, rank, local, dev):
     nodes, tris12, _ = bvh.build_bvh4(tris, leaf_size=4)
     build_s = time.perf_counter() - t0
     org, dirs = bvh.rays_towards(tris, n_rays, seed=20241015 + rank)
+    if a.trace_sorted:  # neighbouring lanes get neighbouring rays: sort by the cell of the origin, then of the target
+        cell = lambda p: np.clip(((p + 1000.0) / 2000.0 * 16).astype(np.int64), 0, 15)
+        co, ct = cell(org), cell(org + dirs)
+        key = ((co[:, 0] * 16 + co[:, 1]) * 16 + co[:, 2]) * 4096 + (ct[:, 0] * 16 + ct[:, 1]) * 16 + ct[:, 2]
+        order = np.argsort(key, kind="stable")
+        org, dirs = org[order], dirs[order]
     N, T = torch.from_numpy(nodes).to(dev), torch.from_numpy(tris12).to(dev)
     o = [torch.from_numpy(np.ascontiguousarray(org[:, c])).to(dev) for c in range(3)]
     d = [torch.from_numpy(np.ascontiguousarray(dirs[:, c])).to(dev) for c in range(3)]
@@ -358,8 +365,8 @@ def run_trace(a, world, rank, local, dev):
         print(json.dumps({"metric": "rays/s (closest hit, BVH4 %s traversal on the datapath ops)" % ("wavefront" if a.trace_wavefront else "depth-first"), "value": round(n_rays * world / per, 1),
                           "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(per * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "trace: 2^%d triangles, 2^%d rays per GPU, leaf size 4, hierarchy built on the host in %.1f s (not timed)" % (
-                              a.trace_log2_tris, a.trace_log2_rays, build_s)},
+                          "config": {"workload": "trace: 2^%d triangles, 2^%d %s rays per GPU, leaf size 4, hierarchy built on the host in %.1f s (not timed)" % (
+                              a.trace_log2_tris, a.trace_log2_rays, "cell-sorted" if a.trace_sorted else "unsorted", build_s)},
                           "per_call": {k: int(v) for k, v in stats.items()}, "hit_fraction": round(hits, 4),
                           "box_ops_per_s": round(stats["box_ops"] / per, 1), "tri_ops_per_s": round(stats["tri_ops"] / per, 1)}), flush=True)
     ctx.close()
