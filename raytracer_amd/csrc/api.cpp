@@ -706,7 +706,7 @@ int rt_dp_knn_tree_grouped_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, 
         if (cap > slots) cap = slots;
         if (nq * cap * 8 > (64ull << 30)) return fail(RT_DP_ENOMEM, "candidate slots would need %llu GiB: use rt_dp_knn_tree_euclid16 for this data",
                                                       (unsigned long long)((nq * cap * 8) >> 30));
-        // round 1 covers every query and remembers its box-test ballots (8 bytes per wave and leaf) for the fill pass;
+        // the first pass over the lists covers every query and remembers its box-test ballots (8 bytes per wave and leaf) for the fill pass;
         // later rounds cover the few queries that continue
         const uint32_t *subset = nullptr;
         uint32_t n_sub = n_queries;
