@@ -52,7 +52,7 @@ enum rt_dp_status {
     RT_DP_EOPCODE  = -3, /* opcode > 3 in a bundle stream (cannot occur in the 2-bit RTL field) */
     RT_DP_EHIP     = -4, /* HIP runtime error; see rt_dp_last_error() */
     RT_DP_ENODEV   = -5, /* no usable gfx950 device */
-    RT_DP_EALIGN   = -6, /* a device array is not 4-byte aligned */
+    RT_DP_EALIGN   = -6, /* an array lacks the alignment its entry point asks for (4, 8 or 16 bytes) */
     RT_DP_ENOMEM   = -7  /* host or device allocation failed */
 };
 
