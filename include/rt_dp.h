@@ -396,6 +396,30 @@ typedef struct rt_dp_bvh4 {
 int rt_dp_trace_closest(rt_dp_ctx *ctx, const rt_dp_bvh4 *bvh, const float *const origin[3], const float *const dir[3],
                         uint32_t n_rays, float extent, uint32_t flags, float *out_t, uint32_t *out_tri, uint64_t stats[4]);
 
+/* ---- host-side builders for the structures above ---------------------------------------
+ * No counterpart in the reference.  Plain host arrays in and out, no GPU involved; the caller
+ * uploads the results.  Simple median splits along the widest dimension: index construction is
+ * outside the timed query paths.
+ *
+ * rt_dp_knn_tree_leaves: the n_leaves (a power of two) a point set needs at this leaf_size.
+ * rt_dp_knn_tree_build_host: fills points[n_leaves * leaf_size][16] (pad slots +Inf),
+ *   index[n_leaves * leaf_size] (index_base + position in `points`, 0xFFFFFFFF for a pad),
+ *   lo / hi[n_leaves][16], and (optionally, both or neither) the split planes in heap order:
+ *   split_dim / split_val[n_leaves - 1], node 2^l - 1 + s for segment s of level l; a query goes
+ *   right when its coordinate >= split_val.
+ * rt_dp_knn_home_leaf_host: the leaf each query reaches by descending those planes.
+ * rt_dp_bvh4_max_nodes: rows to allocate for nodes[][32].
+ * rt_dp_bvh4_build_host: tris[n_tris][9] (A xyz, B xyz, C xyz) -> nodes, *n_nodes, the triangles in
+ *   leaf order as [n_tris][12] and order[i] = the caller's index of stored triangle i.           */
+uint32_t rt_dp_knn_tree_leaves(uint32_t n_points, uint32_t leaf_size);
+int rt_dp_knn_tree_build_host(const float *points, uint32_t n_points, uint32_t leaf_size, uint32_t index_base, float *out_points,
+                              uint32_t *out_index, float *out_lo, float *out_hi, uint32_t *out_split_dim, float *out_split_val);
+int rt_dp_knn_home_leaf_host(const float *queries, uint32_t n_queries, uint32_t n_leaves, const uint32_t *split_dim, const float *split_val,
+                             uint32_t *out_home);
+uint32_t rt_dp_bvh4_max_nodes(uint32_t n_tris);
+int rt_dp_bvh4_build_host(const float *tris, uint32_t n_tris, uint32_t leaf_size, float *out_nodes, uint32_t *out_n_nodes, float *out_tris,
+                          uint32_t *out_order);
+
 /* ---- tuning and diagnostics ---------------------------------------------------
  * Kernel-shape knobs (0 = library default), for A/B measurements; results do not
  * depend on them.  ops_per_lane: consecutive box / triangle ops one lane owns

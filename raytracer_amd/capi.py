@@ -124,6 +124,7 @@ class KnnTree(C.Structure):
 
 EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize",
            "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_knn_angular16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
+           "rt_dp_knn_tree_leaves", "rt_dp_knn_tree_build_host", "rt_dp_knn_home_leaf_host", "rt_dp_bvh4_max_nodes", "rt_dp_bvh4_build_host",
            "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
 
 
@@ -167,10 +168,17 @@ def load():
     L.rt_dp_knn_tree_grouped_euclid16.argtypes = [vp, C.POINTER(KnnTree), vp, vp, C.c_uint32, C.c_uint32, vp, vp, C.POINTER(C.c_uint64 * 4)]
     L.rt_dp_trace_closest.argtypes = [vp, C.POINTER(Bvh4), C.POINTER(vp * 3), C.POINTER(vp * 3), C.c_uint32, C.c_float, C.c_uint32, vp, vp,
                                       C.POINTER(C.c_uint64 * 4)]
+    L.rt_dp_knn_tree_leaves.argtypes = [C.c_uint32, C.c_uint32]
+    L.rt_dp_knn_tree_build_host.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp]
+    L.rt_dp_knn_home_leaf_host.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]
+    L.rt_dp_bvh4_max_nodes.argtypes = [C.c_uint32]
+    L.rt_dp_bvh4_build_host.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     L.rt_dp_last_error.restype = C.c_char_p
     L.rt_dp_version.restype = C.c_char_p
     for name in EXPORTS:
-        if name not in ("rt_dp_destroy", "rt_dp_last_error", "rt_dp_version"):
+        if name in ("rt_dp_knn_tree_leaves", "rt_dp_bvh4_max_nodes"):
+            getattr(L, name).restype = C.c_uint32
+        elif name not in ("rt_dp_destroy", "rt_dp_last_error", "rt_dp_version"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -430,3 +438,42 @@ def version():
 
 def device_count():
     return load().rt_dp_device_count()
+
+
+def knn_tree_build_host(points, leaf_size=128, index_base=0):
+    """Native k-d index build on host arrays (numpy float32 [n, 16]).  Returns a dict of numpy arrays:
+    points, index, leaf_lo, leaf_hi, split_dim, split_val and n_leaves."""
+    L = load()
+    points = np.ascontiguousarray(points, np.float32).reshape(-1, 16)
+    n = points.shape[0]
+    nl = L.rt_dp_knn_tree_leaves(n, leaf_size)
+    out = {"n_leaves": nl, "leaf_size": leaf_size,
+           "points": np.empty((nl * leaf_size, 16), np.float32), "index": np.empty(nl * leaf_size, np.uint32),
+           "leaf_lo": np.empty((nl, 16), np.float32), "leaf_hi": np.empty((nl, 16), np.float32),
+           "split_dim": np.zeros(max(nl - 1, 1), np.uint32), "split_val": np.zeros(max(nl - 1, 1), np.float32)}
+    _check(L.rt_dp_knn_tree_build_host(points.ctypes.data, n, leaf_size, index_base, out["points"].ctypes.data, out["index"].ctypes.data,
+                                       out["leaf_lo"].ctypes.data, out["leaf_hi"].ctypes.data, out["split_dim"].ctypes.data,
+                                       out["split_val"].ctypes.data))
+    return out
+
+
+def knn_home_leaf_host(queries, tree):
+    L = load()
+    queries = np.ascontiguousarray(queries, np.float32).reshape(-1, 16)
+    home = np.empty(queries.shape[0], np.uint32)
+    _check(L.rt_dp_knn_home_leaf_host(queries.ctypes.data, queries.shape[0], tree["n_leaves"], tree["split_dim"].ctypes.data,
+                                      tree["split_val"].ctypes.data, home.ctypes.data))
+    return home
+
+
+def bvh4_build_host(tris, leaf_size=4):
+    """Native BVH4 build on host arrays (numpy float32 [n, 9]).  Returns (nodes [m, 32], tris12 [n, 12], order [n])."""
+    L = load()
+    tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
+    n = tris.shape[0]
+    nodes = np.empty((L.rt_dp_bvh4_max_nodes(n), 32), np.float32)
+    tris12 = np.empty((n, 12), np.float32)
+    order = np.empty(n, np.uint32)
+    m = C.c_uint32(0)
+    _check(L.rt_dp_bvh4_build_host(tris.ctypes.data, n, leaf_size, nodes.ctypes.data, C.byref(m), tris12.ctypes.data, order.ctypes.data))
+    return nodes[:m.value].copy(), tris12, order
