@@ -1,0 +1,53 @@
+"""bench.py's output contract: one JSON line with the agreed fields, alone and under a two-rank launch (both ranks
+on the one GPU, control collectives over gloo: a rehearsal of the N > 1 path, its rates mean nothing)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIELDS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+          "data", "config", "roofline", "cpu_baseline"]
+
+
+def check_line(out, n_gpus, steps, warmup):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    d = json.loads(lines[0])
+    for f in FIELDS:
+        assert f in d, f
+    assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    return d
+
+
+@pytest.mark.gpu
+def test_single_process_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--log2-ops", "20", "--only", "box",
+                        "--cpu-seconds", "1"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = check_line(r.stdout, 1, 3, 1)
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "ops/s" and "sample" in c
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_line():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RT_DP_REHEARSE_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--log2-ops", "20"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = check_line(r.stdout, 2, 3, 1)
+    assert d["cpu_baseline"] is None and set(d["per_opcode"]) == {"box", "tri", "euclid", "angular", "mixed"}
