@@ -348,6 +348,20 @@ int rt_dp_knn_tree_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, const fl
 int rt_dp_knn_tree_grouped_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, const float *queries, const uint32_t *home_leaf,
                                     uint32_t n_queries, uint32_t walk_leaves, float *out_dist, uint32_t *out_idx, uint64_t stats[4]);
 
+/* ---- hit-mask compaction behind a Quadbox batch ------------------------------------------
+ * No counterpart in the reference's sources: the consumer step of a traversal loop.  The Quadbox
+ * output lists the children sorted by entry distance with the hits first (UnifiedDatapath.scala:
+ * 1117-1132); this turns the results of n ops (device arrays, as rt_dp_launch wrote them) into one
+ * dense list with an entry per intersected child: ops in batch order, within an op closest first.
+ *   out_item[k]  = item[i], or i when item is NULL            (e.g. the ray of op i)
+ *   out_child[k] = children[4 i + boxIndex], or boxIndex when children is NULL
+ *   out_tmin[k]  = the child's entry distance (skipped when out_tmin is NULL)
+ * *count receives the number of entries the batch has; at most `capacity` are written.  The list
+ * is a pure function of the inputs (offsets come from ballots and a scan, not from atomics).
+ * Device pointers, 4-byte aligned; synchronous.                                              */
+int rt_dp_box_compact(rt_dp_ctx *ctx, const rt_dp_box_out *results, uint64_t n, const uint32_t *item, const uint32_t *children,
+                      uint32_t *out_item, uint32_t *out_child, float *out_tmin, uint64_t capacity, uint64_t *count);
+
 /* ---- closest-hit traversal on the Quadbox and triangle ops ----------------------------
  * No counterpart in the reference's sources, which end at the datapath: this is the loop a
  * consumer runs around it.  The ops are those of UnifiedDatapath.scala (children sorted by

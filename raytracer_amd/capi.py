@@ -123,7 +123,7 @@ class KnnTree(C.Structure):
                 ("points", C.c_void_p), ("index", C.c_void_p), ("leaf_lo", C.c_void_p), ("leaf_hi", C.c_void_p)]
 
 EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize",
-           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_knn_angular16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
+           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_knn_angular16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_box_compact", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
            "rt_dp_knn_tree_leaves", "rt_dp_knn_tree_build_host", "rt_dp_knn_home_leaf_host", "rt_dp_bvh4_max_nodes", "rt_dp_bvh4_build_host",
            "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
 
@@ -166,6 +166,7 @@ def load():
     L.rt_dp_knn_angular16.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.rt_dp_knn_tree_euclid16.argtypes = [vp, C.POINTER(KnnTree), vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     L.rt_dp_knn_tree_grouped_euclid16.argtypes = [vp, C.POINTER(KnnTree), vp, vp, C.c_uint32, C.c_uint32, vp, vp, C.POINTER(C.c_uint64 * 4)]
+    L.rt_dp_box_compact.argtypes = [vp, C.POINTER(BoxOut), C.c_uint64, vp, vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.rt_dp_trace_closest.argtypes = [vp, C.POINTER(Bvh4), C.POINTER(vp * 3), C.POINTER(vp * 3), C.c_uint32, C.c_float, C.c_uint32, vp, vp,
                                       C.POINTER(C.c_uint64 * 4)]
     L.rt_dp_knn_tree_leaves.argtypes = [C.c_uint32, C.c_uint32]
@@ -405,6 +406,23 @@ class Context:
         _check(self._L.rt_dp_knn_tree_grouped_euclid16(self._h, C.byref(ct), queries.data_ptr(), home_leaf.data_ptr(), m, int(walk_leaves),
                                                        out_dist.data_ptr(), out_idx.data_ptr(), C.byref(stats)))
         return {"pairs": stats[0], "groups": stats[1], "candidate_slots": stats[2], "rounds": stats[3]}
+
+    def box_compact(self, tmin, flags, out_item, out_child, out_tmin=None, item=None, children=None):
+        """Dense (item, child[, tmin]) list of the intersected children of a Quadbox batch (torch CUDA tensors).
+        tmin: the four result arrays (or None when out_tmin is None); flags: the packed result word.  Returns the
+        number of entries the batch has (only out_item.shape[0] of them are written)."""
+        ro = BoxOut()
+        keep = set()
+        if tmin is not None:
+            for k in range(4):
+                ro.tmin_out[k] = _ptr(tmin[k], keep)
+        ro.flags = _ptr(flags, keep)
+        n = int(flags.shape[0])
+        count = C.c_uint64(0)
+        p = lambda t: None if t is None else t.data_ptr()
+        _check(self._L.rt_dp_box_compact(self._h, C.byref(ro), n, p(item), p(children), p(out_item), p(out_child), p(out_tmin),
+                                         int(out_item.shape[0]), C.byref(count)))
+        return int(count.value)
 
     def trace_closest(self, nodes, tris, origin, direction, extent, out_t, out_tri, wavefront=False):
         """Closest hit of every ray in a 4-wide hierarchy (torch CUDA tensors).  nodes [m,32] float32, tris [n,12] float32,

@@ -778,6 +778,41 @@ int rt_dp_knn_tree_grouped_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, 
     return RT_DP_OK;
 }
 
+int rt_dp_box_compact(rt_dp_ctx *ctx, const rt_dp_box_out *results, uint64_t n, const uint32_t *item, const uint32_t *children,
+                      uint32_t *out_item, uint32_t *out_child, float *out_tmin, uint64_t capacity, uint64_t *count) {
+    if (!ctx || !results || !count) return fail(RT_DP_ENULL, "rt_dp_box_compact: NULL argument");
+    *count = 0;
+    if (n == 0) return RT_DP_OK;
+    if (n > kMaxOps) return fail(RT_DP_EINVAL, "n = %llu is not representable (limit 2^40)", (unsigned long long)n);
+    if (!results->flags || (capacity && (!out_item || !out_child))) return fail(RT_DP_ENULL, "rt_dp_box_compact: NULL array");
+    uintptr_t acc = reinterpret_cast<uintptr_t>(results->flags) | reinterpret_cast<uintptr_t>(item) | reinterpret_cast<uintptr_t>(children) |
+                    reinterpret_cast<uintptr_t>(out_item) | reinterpret_cast<uintptr_t>(out_child) | reinterpret_cast<uintptr_t>(out_tmin);
+    if (out_tmin)
+        for (int k = 0; k < 4; ++k) {
+            if (!results->tmin_out[k]) return fail(RT_DP_ENULL, "rt_dp_box_compact: out_tmin needs all four tmin_out arrays");
+            acc |= reinterpret_cast<uintptr_t>(results->tmin_out[k]);
+        }
+    if (acc & 3u) return fail(RT_DP_EALIGN, "rt_dp_box_compact: arrays must be 4-byte aligned");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipDeviceSynchronize());  // the results may still be in production on a caller stream
+    const uint64_t nblk = (n + 255) / 256;
+    const size_t o_cnt = 0, o_off = align_up(nblk * 4), o_tot = o_off + align_up(nblk * 8);
+    int rc = regrow(ctx->d_trace, ctx->trace_bytes, o_tot + 256, "compaction offsets");
+    if (rc != RT_DP_OK) return rc;
+    uint32_t *blockcnt = reinterpret_cast<uint32_t *>(ctx->d_trace + o_cnt);
+    unsigned long long *offsets64 = reinterpret_cast<unsigned long long *>(ctx->d_trace + o_off);
+    unsigned long long *total = reinterpret_cast<unsigned long long *>(ctx->d_trace + o_tot);
+    const float *tm[4] = {results->tmin_out[0], results->tmin_out[1], results->tmin_out[2], results->tmin_out[3]};
+    HIP_TRY(compact_hits(results->flags, tm, n, item, children, blockcnt, offsets64, total, capacity, out_item, out_child, out_tmin, s));
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, total, sizeof h, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *count = h;
+    return RT_DP_OK;
+}
+
 int rt_dp_trace_closest(rt_dp_ctx *ctx, const rt_dp_bvh4 *bvh, const float *const origin[3], const float *const dir[3],
                         uint32_t n_rays, float extent, uint32_t flags, float *out_t, uint32_t *out_tri, uint64_t stats[4]) {
     if (!ctx || !bvh || !origin || !dir) return fail(RT_DP_ENULL, "rt_dp_trace_closest: NULL argument");

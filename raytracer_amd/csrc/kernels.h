@@ -82,6 +82,11 @@ hipError_t stream_fused_eval(const uint32_t *in, uint64_t n, uint64_t capacity, 
                              StreamSideView *view, hipStream_t s);
 hipError_t stream_fused_fold(const StreamSideView &v, uint64_t n, const float *state_in, float *state_out, uint32_t *out, hipStream_t s);
 
+// hit-mask compaction behind a Quadbox batch (compact.hip); blockcnt [ceil(n/256)] u32, offsets64 likewise u64, total one u64
+hipError_t compact_hits(const uint32_t *flags, const float *const tmin[4], uint64_t n, const uint32_t *item, const uint32_t *children,
+                        uint32_t *blockcnt, unsigned long long *offsets64, unsigned long long *total, uint64_t capacity, uint32_t *out_item,
+                        uint32_t *out_child, float *out_tmin, hipStream_t s);
+
 // traversal driver (trace.hip); queues hold (ray, node or leaf reference) pairs of 8 bytes
 hipError_t trace_validate(const float *nodes, uint32_t n_nodes, uint32_t n_tris, uint32_t *bad, hipStream_t s);
 hipError_t trace_init(const float *const origin[3], const float *const dir[3], uint32_t n, float extent, float *rays,
