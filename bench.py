@@ -72,11 +72,13 @@ def parse():
     p.add_argument("--knn-data", default="uniform", help="uniform: U(-1,1)^16 (the named configuration); clustered: 256 Gaussian clusters, sigma 0.05")
     p.add_argument("--knn-leaf", type=int, default=128, help="points per tree leaf")
     p.add_argument("--knn-splits", type=int, default=0, help="point splits per query block (0 = chosen by the library front-end)")
+    p.add_argument("--derive", type=int, default=0, help="1: box / tri workloads derive inv / shear / k from dir inside the kernels "
+                   "(RT_DP_F_DERIVE_RAY: 144 and 72 algorithmic bytes per op); not the headline format")
     p.add_argument("--sweep", action="store_true", help="A/B the kernel shapes instead of the timed run")
     return p.parse_args()
 
 
-def make_batches(n, dev, which, stagger_kib=0):
+def make_batches(n, dev, which, stagger_kib=0, derive=False):
     """Resident operand / result arrays and one capi.Batch per workload."""
     out = {}
     i32, f32 = torch.int32, torch.float32
@@ -111,13 +113,13 @@ def make_batches(n, dev, which, stagger_kib=0):
         return q, c, ctl, torch.empty(ctl.shape[0], dtype=f32, device=dev), torch.empty(ctl.shape[0], dtype=f32, device=dev)
 
     if "box" in which:
-        b = capi.Batch()
+        b = capi.Batch().derive_ray(derive)
         fields, tmin, flags = box(n)
         b.set_box(fields, tmin, flags)
         b.box_fields = fields
         out["box"] = (b.finalize(), {"box": n})
     if "tri" in which:
-        b = capi.Batch()
+        b = capi.Batch().derive_ray(derive)   # derive: the three shear arrays stand in for the ray direction
         b.set_tri(*tri(n))
         out["tri"] = (b.finalize(), {"tri": n})
     if "euclid" in which:
@@ -133,7 +135,7 @@ def make_batches(n, dev, which, stagger_kib=0):
     if "mixed" in which:
         # opcode ~ U{0..3}: a quarter of the stream per opcode, opcode-sorted segments
         q = n // 4
-        b = capi.Batch()
+        b = capi.Batch().derive_ray(derive)
         b.set_box(*box(q))
         b.set_tri(*tri(q))
         e, a = euc(q), ang(q)
@@ -229,6 +231,8 @@ def roofline(counts, dev_ms):
 def load_valu(counts):
     """Fraction of the FP32 VALU issue peak from the committed SQ_INSTS_VALU pass (single-opcode batches only)."""
     try:
+        if BYTES["box"] != 156:
+            return None
         per_unit = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         (k,) = counts.keys()
         return per_unit[k].get("valu_issue_fraction")
@@ -240,7 +244,7 @@ def load_traffic(counts):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json:
     {"box": bytes_per_op, ...}, already corrected as the gfx950 counter notes require), or None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(path):
+    if not os.path.exists(path) or BYTES["box"] != 156:   # the committed passes measured the plain operand format
         return None
     try:
         per_unit = json.load(open(path))
@@ -464,7 +468,9 @@ def main():
     which = [a.only] if a.only else ["box", "tri", "euclid", "angular", "mixed"]
     ctx = capi.Context(device=local)
     ctx.set_tuning(a.ops_per_lane, a.nontemporal, a.vec_tile, a.variant, a.vec_passes)
-    batches = make_batches(n, dev, which, a.stagger_kib)
+    if a.derive:
+        BYTES.update(box=144, tri=72)
+    batches = make_batches(n, dev, which, a.stagger_kib, bool(a.derive))
     torch.cuda.synchronize()
 
     if a.sweep:
@@ -492,7 +498,7 @@ def main():
         "config": {"workload": "%s: %s random ray-vs-4-AABB box ops per GPU, SoA fp32 operands resident in HBM" % (head, size_text)
                    if head == "box" else "%s, %s units per GPU" % (head, size_text),
                    "ops_per_gpu": r["units_per_gpu"], "bytes_per_op": BYTES.get(head), "sharding": "independent op streams per GPU, no collective",
-                   "tuning": {"ops_per_lane": a.ops_per_lane, "nontemporal": a.nontemporal, "vec_tile": a.vec_tile, "variant": a.variant, "vec_passes": a.vec_passes}},
+                   "tuning": {"ops_per_lane": a.ops_per_lane, "nontemporal": a.nontemporal, "vec_tile": a.vec_tile, "variant": a.variant, "vec_passes": a.vec_passes, "derive": a.derive}},
         "roofline": r["roofline"],
     }
     if rank == 0:

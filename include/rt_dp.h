@@ -60,7 +60,14 @@ enum rt_dp_status {
 #define RT_DP_F_DEVICE_PTRS 0x1u /* every array pointer in the batch and in the result is a device pointer
                                     of the context's GPU; without it they are host pointers and the library
                                     stages them through its own device buffers */
-#define RT_DP_F_ALL_FLAGS   0x1u
+#define RT_DP_F_DERIVE_RAY  0x2u /* the ray's derived fields are computed inside the box and triangle kernels
+                                    from dir, exactly as rt_dp_ray_prepare would write them (the reference
+                                    derives them in its software model before a record is poked:
+                                    SW_Data.scala:36-82): box.inv[] and tri.shear[], tri.k are not read and
+                                    may be NULL, tri.dir[] is read instead.  12 B (box) and 4 B (triangle)
+                                    less traffic per op; results equal those of the two-step path bit for
+                                    bit */
+#define RT_DP_F_ALL_FLAGS   0x3u
 
 /* ---- opcode 1: Quadbox --------------------------------------------------
  * Live operands of EnhancedInputBundle for this opcode (IOSpec.scala:54-91,
@@ -96,6 +103,7 @@ typedef struct rt_dp_tri_in {
     const float    *vtx[3][3]; /* triangle.{A,B,C}.{x,y,z} */
     const uint32_t *k;         /* ray.kx | ray.ky << 2 | ray.kz << 4; a selector value of 3 reads z,
                                   like Float3.at (IOSpec.scala:41-51) */
+    const float    *dir[3];    /* ray.dir: read only under RT_DP_F_DERIVE_RAY, in place of shear and k */
 } rt_dp_tri_in;
 
 typedef struct rt_dp_tri_out {

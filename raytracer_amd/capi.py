@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "librt_dp.so")
 
 OP_TRIANGLE, OP_QUADBOX, OP_EUCLIDEAN, OP_ANGULAR = 0, 1, 2, 3
 F_DEVICE_PTRS = 0x1
+F_DERIVE_RAY = 0x2
 
 OK, EINVAL, ENULL, EOPCODE, EHIP, ENODEV, EALIGN, ENOMEM = 0, -1, -2, -3, -4, -5, -6, -7
 
@@ -38,7 +39,7 @@ class BoxOut(C.Structure):
 
 
 class TriIn(C.Structure):
-    _fields_ = [("org", _fp * 3), ("shear", _fp * 3), ("vtx", (_fp * 3) * 3), ("k", _fp)]
+    _fields_ = [("org", _fp * 3), ("shear", _fp * 3), ("vtx", (_fp * 3) * 3), ("k", _fp), ("dir", _fp * 3)]
 
 
 class TriOut(C.Structure):
@@ -219,6 +220,7 @@ class Batch:
         self.rb.struct_size = C.sizeof(ResultBatch)
         self._keep = []
         self._kinds = set()
+        self._derive = False
 
     def _p(self, x):
         self._keep.append(x)
@@ -231,7 +233,7 @@ class Batch:
         for a in range(3):
             b.org[a] = self._p(fields[a])
             b.dir[a] = self._p(fields[3 + a])
-            b.inv[a] = self._p(fields[6 + a])
+            b.inv[a] = None if self._derive else self._p(fields[6 + a])
         b.extent = self._p(fields[9])
         for bi in range(4):
             for f in range(6):
@@ -247,15 +249,18 @@ class Batch:
         t = self.ob.tri
         for a in range(3):
             t.org[a] = self._p(fields[a])
-            t.shear[a] = self._p(fields[3 + a])
+            if self._derive:
+                t.dir[a] = self._p(fields[3 + a])
+            else:
+                t.shear[a] = self._p(fields[3 + a])
         for v in range(3):
             for a in range(3):
                 t.vtx[v][a] = self._p(fields[6 + 3 * v + a])
-        t.k = self._p(k)
+        t.k = None if self._derive else self._p(k)
         self.rb.tri.t_num = self._p(t_num)
         self.rb.tri.t_denom = self._p(t_denom)
         self.rb.tri.hit = self._p(hit)
-        self.ob.n[OP_TRIANGLE] = int(k.shape[0]) if n is None else int(n)
+        self.ob.n[OP_TRIANGLE] = int(fields[0].shape[0]) if n is None else int(n)
 
     def set_euclid(self, a, b, ctl, acc, n=None):
         self.ob.euc.a, self.ob.euc.b, self.ob.euc.ctl = self._p(a), self._p(b), self._p(ctl)
@@ -271,7 +276,13 @@ class Batch:
     def finalize(self):
         if len(self._kinds) > 1:
             raise ValueError("a batch must not mix host and device arrays")
-        self.ob.flags = F_DEVICE_PTRS if "cuda" in self._kinds else 0
+        self.ob.flags = (F_DEVICE_PTRS if "cuda" in self._kinds else 0) | (F_DERIVE_RAY if self._derive else 0)
+        return self
+
+    def derive_ray(self, on=True):
+        """RT_DP_F_DERIVE_RAY: inv / shear / k come from dir inside the kernels.  In this mode set_box ignores
+        fields[6:9] (they may be None) and set_tri takes the ray direction in fields[3:6], k may be None."""
+        self._derive = bool(on)
         return self
 
 

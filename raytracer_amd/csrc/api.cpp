@@ -97,17 +97,26 @@ int check_batch(const rt_dp_op_batch *in, const rt_dp_result_batch *out) {
         if (reinterpret_cast<uintptr_t>(ptr) & 3u) return fail(RT_DP_EALIGN, "%s is not 4-byte aligned", what); \
     } while (0)
 
+    const bool derive = (in->flags & RT_DP_F_DERIVE_RAY) != 0;
     if (in->n[RT_DP_OP_TRIANGLE]) {
-        for (int a = 0; a < 3; ++a) { NEED(in->tri.org[a], "tri.org[]"); NEED(in->tri.shear[a], "tri.shear[]"); }
+        for (int a = 0; a < 3; ++a) {
+            NEED(in->tri.org[a], "tri.org[]");
+            if (derive) NEED(in->tri.dir[a], "tri.dir[]");
+            else NEED(in->tri.shear[a], "tri.shear[]");
+        }
         for (int v = 0; v < 3; ++v)
             for (int a = 0; a < 3; ++a) NEED(in->tri.vtx[v][a], "tri.vtx[][]");
-        NEED(in->tri.k, "tri.k");
+        if (!derive) NEED(in->tri.k, "tri.k");
         NEED(out->tri.t_num, "result tri.t_num");
         NEED(out->tri.t_denom, "result tri.t_denom");
         NEED(out->tri.hit, "result tri.hit");
     }
     if (in->n[RT_DP_OP_QUADBOX]) {
-        for (int a = 0; a < 3; ++a) { NEED(in->box.org[a], "box.org[]"); NEED(in->box.dir[a], "box.dir[]"); NEED(in->box.inv[a], "box.inv[]"); }
+        for (int a = 0; a < 3; ++a) {
+            NEED(in->box.org[a], "box.org[]");
+            NEED(in->box.dir[a], "box.dir[]");
+            if (!derive) NEED(in->box.inv[a], "box.inv[]");
+        }
         NEED(in->box.extent, "box.extent");
         for (int b = 0; b < 4; ++b)
             for (int f = 0; f < 6; ++f) NEED(in->box.aabb[b][f], "box.aabb[][]");
@@ -127,11 +136,11 @@ int check_batch(const rt_dp_op_batch *in, const rt_dp_result_batch *out) {
     return RT_DP_OK;
 }
 
-void fill_box(BoxArgs &a, const rt_dp_box_in &in, const rt_dp_box_out &out) {
+void fill_box(BoxArgs &a, const rt_dp_box_in &in, const rt_dp_box_out &out, bool derive = false) {
     int f = 0;
     for (int i = 0; i < 3; ++i) a.in[f++] = in.org[i];
     for (int i = 0; i < 3; ++i) a.in[f++] = in.dir[i];
-    for (int i = 0; i < 3; ++i) a.in[f++] = in.inv[i];
+    for (int i = 0; i < 3; ++i) a.in[f++] = derive ? nullptr : in.inv[i];
     a.in[f++] = in.extent;
     for (int b = 0; b < 4; ++b)
         for (int k = 0; k < 6; ++k) a.in[f++] = in.aabb[b][k];
@@ -139,13 +148,13 @@ void fill_box(BoxArgs &a, const rt_dp_box_in &in, const rt_dp_box_out &out) {
     a.flags = out.flags;
 }
 
-void fill_tri(TriArgs &a, const rt_dp_tri_in &in, const rt_dp_tri_out &out) {
+void fill_tri(TriArgs &a, const rt_dp_tri_in &in, const rt_dp_tri_out &out, bool derive = false) {
     int f = 0;
     for (int i = 0; i < 3; ++i) a.in[f++] = in.org[i];
-    for (int i = 0; i < 3; ++i) a.in[f++] = in.shear[i];
+    for (int i = 0; i < 3; ++i) a.in[f++] = derive ? in.dir[i] : in.shear[i];
     for (int v = 0; v < 3; ++v)
         for (int i = 0; i < 3; ++i) a.in[f++] = in.vtx[v][i];
-    a.k = in.k;
+    a.k = derive ? nullptr : in.k;
     a.t_num = out.t_num;
     a.t_denom = out.t_denom;
     a.hit = out.hit;
@@ -155,15 +164,16 @@ void fill_tri(TriArgs &a, const rt_dp_tri_in &in, const rt_dp_tri_out &out) {
 int launch_device(rt_dp_ctx *ctx, const rt_dp_op_batch *in, const rt_dp_result_batch *out, hipStream_t s) {
     const uint64_t n_tri = in->n[RT_DP_OP_TRIANGLE], n_box = in->n[RT_DP_OP_QUADBOX];
     const uint64_t n_euc = in->n[RT_DP_OP_EUCLIDEAN], n_ang = in->n[RT_DP_OP_ANGULAR];
+    const bool derive = (in->flags & RT_DP_F_DERIVE_RAY) != 0;
     if (n_box) {
         BoxArgs a;
-        fill_box(a, in->box, out->box);
-        HIP_TRY(launch_box(a, n_box, ctx->tuning, s));
+        fill_box(a, in->box, out->box, derive);
+        HIP_TRY(launch_box(a, n_box, ctx->tuning, s, derive));
     }
     if (n_tri) {
         TriArgs a;
-        fill_tri(a, in->tri, out->tri);
-        HIP_TRY(launch_tri(a, n_tri, ctx->tuning, s));
+        fill_tri(a, in->tri, out->tri, derive);
+        HIP_TRY(launch_tri(a, n_tri, ctx->tuning, s, derive));
     }
     if (!ctx->extended) {
         // baseline datapath: opcodes 2/3 flow through untouched, outputs stay 0 and the
@@ -218,15 +228,24 @@ int eval_host(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *out)
 
     const uint64_t n_tri = in->n[RT_DP_OP_TRIANGLE], n_box = in->n[RT_DP_OP_QUADBOX];
     const uint64_t n_euc = in->n[RT_DP_OP_EUCLIDEAN], n_ang = in->n[RT_DP_OP_ANGULAR];
+    const bool derive = (in->flags & RT_DP_F_DERIVE_RAY) != 0;
     if (n_tri) {
-        for (int a = 0; a < 3; ++a) { IN_ARR(din.tri.org[a], n_tri, 4); IN_ARR(din.tri.shear[a], n_tri, 4); }
+        for (int a = 0; a < 3; ++a) {
+            IN_ARR(din.tri.org[a], n_tri, 4);
+            if (derive) IN_ARR(din.tri.dir[a], n_tri, 4);
+            else IN_ARR(din.tri.shear[a], n_tri, 4);
+        }
         for (int v = 0; v < 3; ++v)
             for (int a = 0; a < 3; ++a) IN_ARR(din.tri.vtx[v][a], n_tri, 4);
-        IN_ARR(din.tri.k, n_tri, 4);
+        if (!derive) IN_ARR(din.tri.k, n_tri, 4);
         OUT_ARR(dout.tri.t_num, n_tri, 4); OUT_ARR(dout.tri.t_denom, n_tri, 4); OUT_ARR(dout.tri.hit, n_tri, 4);
     }
     if (n_box) {
-        for (int a = 0; a < 3; ++a) { IN_ARR(din.box.org[a], n_box, 4); IN_ARR(din.box.dir[a], n_box, 4); IN_ARR(din.box.inv[a], n_box, 4); }
+        for (int a = 0; a < 3; ++a) {
+            IN_ARR(din.box.org[a], n_box, 4);
+            IN_ARR(din.box.dir[a], n_box, 4);
+            if (!derive) IN_ARR(din.box.inv[a], n_box, 4);
+        }
         IN_ARR(din.box.extent, n_box, 4);
         for (int b = 0; b < 4; ++b)
             for (int f = 0; f < 6; ++f) IN_ARR(din.box.aabb[b][f], n_box, 4);

@@ -51,8 +51,8 @@ struct Tuning {
     int vec_passes;    // Euclidean / angular: 16-byte load pairs in flight per lane and sub-tile (2, 4 or 8)
 };
 
-hipError_t launch_box(const BoxArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
-hipError_t launch_tri(const TriArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
+hipError_t launch_box(const BoxArgs &args, uint64_t n, const Tuning &t, hipStream_t stream, bool derive = false);  // derive: in[6..8] unused
+hipError_t launch_tri(const TriArgs &args, uint64_t n, const Tuning &t, hipStream_t stream, bool derive = false);  // derive: in[3..5] = dir, k unused
 hipError_t launch_euclid(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
 hipError_t launch_angular(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
 

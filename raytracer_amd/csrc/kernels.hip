@@ -86,6 +86,26 @@ __global__ __launch_bounds__(256) void k_box(BoxArgs args, uint64_t first, uint6
     box_eval_store<V, NT>(args, i0, x);
 }
 
+// The same with the ray's reciprocals derived in the kernel: inv = 1.0f / dir, correctly rounded, as the
+// reference's software model fills the field (src/test/scala/raytracer_datapath/raytracer_gold/SW_Data.scala:56-61).
+// Three operand arrays fewer: 144 B per op instead of 156.
+template <int V, bool NT>
+__global__ __launch_bounds__(256) void k_box_derive(BoxArgs args, uint64_t first, uint64_t groups) {
+    using F = typename Pack<V>::F;
+    const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (g >= groups) return;
+    const uint64_t i0 = first + g * V;
+    F x[kBoxFields];
+#pragma unroll
+    for (int f = 0; f < kBoxFields; ++f)
+        if (f < 6 || f > 8) x[f] = ld<F, NT>(args.in[f] + i0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int v = 0; v < V; ++v) lane_set<V>(x[6 + c], v, canon_nan(1.0f / lane_get<V>(x[3 + c], v)));
+    box_eval_store<V, NT>(args, i0, x);
+}
+
 // Diagnostic shape for bandwidth accounting (variant 10, never selected by default): the
 // box kernel's loads and stores with a trivial reduction in place of the datapath
 // arithmetic, i.e. what the memory pattern alone costs.  Its outputs are meaningless.
@@ -146,6 +166,32 @@ __global__ __launch_bounds__(256) void k_tri(TriArgs args, uint64_t first, uint6
     typename Pack<V>::F x[kTriFields];
     typename Pack<V>::U kk;
     tri_load<V, NT>(args, i0, x, kk);
+    tri_eval_store<V, NT>(args, i0, x, kk);
+}
+
+// The same with shear and the axis selectors derived in the kernel from the ray direction, which then
+// takes the place of shear in fields 3..5 (ray_derive): no selector array, 72 B per op instead of 76.
+template <int V, bool NT>
+__global__ __launch_bounds__(256) void k_tri_derive(TriArgs args, uint64_t first, uint64_t groups) {
+    using F = typename Pack<V>::F;
+    using U = typename Pack<V>::U;
+    const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (g >= groups) return;
+    const uint64_t i0 = first + g * V;
+    F x[kTriFields];
+    U kk;
+#pragma unroll
+    for (int f = 0; f < kTriFields; ++f) x[f] = ld<F, NT>(args.in[f] + i0);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const float d[3] = {lane_get<V>(x[3], v), lane_get<V>(x[4], v), lane_get<V>(x[5], v)};
+        float inv[3], sh[3];
+        uint32_t k;
+        ray_derive(d, inv, k, sh);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) lane_set<V>(x[3 + c], v, sh[c]);
+        lane_setu<V>(kk, v, k);
+    }
     tri_eval_store<V, NT>(args, i0, x, kk);
 }
 
@@ -393,6 +439,16 @@ template <bool NT> static void launch_tri_v(const TriArgs &a, uint64_t n, int v,
     else if (v == 2) RTDP_LAUNCH_OPS(k_tri, a, n, 2, NT, s);
     else RTDP_LAUNCH_OPS(k_tri, a, n, 1, NT, s);
 }
+template <bool NT> static void launch_box_derive_v(const BoxArgs &a, uint64_t n, int v, hipStream_t s) {
+    if (v == 4) RTDP_LAUNCH_OPS(k_box_derive, a, n, 4, NT, s);
+    else if (v == 2) RTDP_LAUNCH_OPS(k_box_derive, a, n, 2, NT, s);
+    else RTDP_LAUNCH_OPS(k_box_derive, a, n, 1, NT, s);
+}
+template <bool NT> static void launch_tri_derive_v(const TriArgs &a, uint64_t n, int v, hipStream_t s) {
+    if (v == 4) RTDP_LAUNCH_OPS(k_tri_derive, a, n, 4, NT, s);
+    else if (v == 2) RTDP_LAUNCH_OPS(k_tri_derive, a, n, 2, NT, s);
+    else RTDP_LAUNCH_OPS(k_tri_derive, a, n, 1, NT, s);
+}
 
 // Operand and result streams are touched exactly once, so by default they carry the
 // nt hint and do not displace each other in L2 / Infinity Cache.
@@ -405,33 +461,39 @@ static int pick_v(int requested, int align_bytes, int dflt) {
     return v < 1 ? 1 : v;
 }
 
-hipError_t launch_box(const BoxArgs &args, uint64_t n, const Tuning &t, hipStream_t stream) {
+hipError_t launch_box(const BoxArgs &args, uint64_t n, const Tuning &t, hipStream_t stream, bool derive) {
     if (n == 0) return hipSuccess;
-    if (t.variant == 10) {  // diagnostic: memory pattern only, 8-byte-aligned even-sized batches
+    if (t.variant == 10 && !derive) {  // diagnostic: memory pattern only, 8-byte-aligned even-sized batches
         const uint64_t groups = n / 2;
         hipLaunchKernelGGL((k_box_pattern<2>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, args, groups);
         return hipGetLastError();
     }
     const void *ptrs[kBoxFields + 5];
-    for (int i = 0; i < kBoxFields; ++i) ptrs[i] = args.in[i];
+    for (int i = 0; i < kBoxFields; ++i) ptrs[i] = (derive && i >= 6 && i <= 8) ? nullptr : args.in[i];
     for (int i = 0; i < 4; ++i) ptrs[kBoxFields + i] = args.tmin[i];
     ptrs[kBoxFields + 4] = args.flags;
     const int v = pick_v(t.ops_per_lane, min_align(ptrs, kBoxFields + 5), 2);
-    if (use_nt(t)) launch_box_v<true>(args, n, v, stream);
+    if (derive) {
+        if (use_nt(t)) launch_box_derive_v<true>(args, n, v, stream);
+        else launch_box_derive_v<false>(args, n, v, stream);
+    } else if (use_nt(t)) launch_box_v<true>(args, n, v, stream);
     else launch_box_v<false>(args, n, v, stream);
     return hipGetLastError();
 }
 
-hipError_t launch_tri(const TriArgs &args, uint64_t n, const Tuning &t, hipStream_t stream) {
+hipError_t launch_tri(const TriArgs &args, uint64_t n, const Tuning &t, hipStream_t stream, bool derive) {
     if (n == 0) return hipSuccess;
     const void *ptrs[kTriFields + 4];
     for (int i = 0; i < kTriFields; ++i) ptrs[i] = args.in[i];
-    ptrs[kTriFields] = args.k;
+    ptrs[kTriFields] = derive ? nullptr : args.k;
     ptrs[kTriFields + 1] = args.t_num;
     ptrs[kTriFields + 2] = args.t_denom;
     ptrs[kTriFields + 3] = args.hit;
     const int v = pick_v(t.ops_per_lane, min_align(ptrs, kTriFields + 4), 2);
-    if (use_nt(t)) launch_tri_v<true>(args, n, v, stream);
+    if (derive) {
+        if (use_nt(t)) launch_tri_derive_v<true>(args, n, v, stream);
+        else launch_tri_derive_v<false>(args, n, v, stream);
+    } else if (use_nt(t)) launch_tri_v<true>(args, n, v, stream);
     else launch_tri_v<false>(args, n, v, stream);
     return hipGetLastError();
 }
