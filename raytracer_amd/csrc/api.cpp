@@ -51,6 +51,7 @@ struct rt_dp_ctx {
     // grow-only staging for host-pointer batches
     char *d_stage = nullptr;
     size_t stage_bytes = 0;
+    char *h_stage = nullptr;  // pinned mirror of the front of d_stage, for small host-pointer batches
     // grow-only workspace of the device-side record stream path (slots, block offsets)
     char *d_stream = nullptr;
     size_t stream_bytes = 0;
@@ -210,6 +211,8 @@ struct Span { const void *src; void *dst_host; size_t bytes; size_t off; };
 
 size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
 
+constexpr size_t kPinnedStage = size_t(8) << 20;  // host-pointer batches up to this size travel through pinned memory
+
 // Host-pointer batch: stage through the context's device buffer.
 int eval_host(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *out) {
     std::vector<Span> ins, outs;
@@ -218,8 +221,10 @@ int eval_host(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *out)
     rt_dp_result_batch dout = *out;
     din.flags |= RT_DP_F_DEVICE_PTRS;
 
-    auto add_in = [&](const void *host, size_t bytes) -> size_t { ins.push_back({host, nullptr, bytes, total}); size_t o = total; total += align_up(bytes); return o; };
-    auto add_out = [&](void *host, size_t bytes) -> size_t { outs.push_back({nullptr, host, bytes, total}); size_t o = total; total += align_up(bytes); return o; };
+    // inputs first, outputs behind them: each side is one contiguous range of the staging buffer
+    size_t in_total = 0, out_total = 0;
+    auto add_in = [&](const void *host, size_t bytes) -> size_t { ins.push_back({host, nullptr, bytes, in_total}); size_t o = in_total; in_total += align_up(bytes); return o; };
+    auto add_out = [&](void *host, size_t bytes) -> size_t { outs.push_back({nullptr, host, bytes, out_total}); size_t o = out_total; out_total += align_up(bytes); return o; };
 
     std::vector<std::pair<const void **, size_t>> fix_in;  // (field address, offset)
     std::vector<std::pair<void **, size_t>> fix_out;
@@ -262,20 +267,43 @@ int eval_host(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *out)
     }
 #undef IN_ARR
 #undef OUT_ARR
+    total = in_total + out_total;
     if (total == 0) return RT_DP_OK;
+    for (auto &s : outs) s.off += in_total;
+    for (auto &f : fix_out) f.second += in_total;
 
     if (total > ctx->stage_bytes) {
         if (ctx->d_stage) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(ctx->d_stage)); ctx->d_stage = nullptr; ctx->stage_bytes = 0; }
         size_t want = total + total / 4;
+        if (want < kPinnedStage) want = kPinnedStage;
         hipError_t e = hipMalloc(&ctx->d_stage, want);
         if (e != hipSuccess) return fail(RT_DP_ENOMEM, "hipMalloc(%zu) for staging failed: %s", want, hipGetErrorString(e));
         ctx->stage_bytes = want;
     }
     for (auto &f : fix_in) *f.first = ctx->d_stage + f.second;
     for (auto &f : fix_out) *f.first = ctx->d_stage + f.second;
-    for (auto &s : ins) HIP_TRY(hipMemcpyAsync(ctx->d_stage + s.off, s.src, s.bytes, hipMemcpyHostToDevice, ctx->stream));
+
+    // Small batches (the testbench's 100-op suites): dozens of tiny pageable copies cost more than the work.
+    // Gather the operands in a pinned mirror, move each side with one copy.
+    const bool pinned = total <= kPinnedStage;
+    if (pinned && !ctx->h_stage) {
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_stage), kPinnedStage, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(RT_DP_ENOMEM, "hipHostMalloc(%zu) for staging failed: %s", kPinnedStage, hipGetErrorString(e));
+    }
+    if (pinned) {
+        for (auto &s : ins) memcpy(ctx->h_stage + s.off, s.src, s.bytes);
+        if (in_total) HIP_TRY(hipMemcpyAsync(ctx->d_stage, ctx->h_stage, in_total, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        for (auto &s : ins) HIP_TRY(hipMemcpyAsync(ctx->d_stage + s.off, s.src, s.bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
     int rc = launch_device(ctx, &din, &dout, ctx->stream);
     if (rc != RT_DP_OK) return rc;
+    if (pinned) {
+        if (out_total) HIP_TRY(hipMemcpyAsync(ctx->h_stage + in_total, ctx->d_stage + in_total, out_total, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (auto &s : outs) memcpy(s.dst_host, ctx->h_stage + s.off, s.bytes);
+        return RT_DP_OK;
+    }
     for (auto &s : outs) HIP_TRY(hipMemcpyAsync(s.dst_host, ctx->d_stage + s.off, s.bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RT_DP_OK;
@@ -350,6 +378,7 @@ void rt_dp_destroy(rt_dp_ctx *ctx) {
     DeviceGuard guard(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->d_stream) (void)hipFree(ctx->d_stream);
     if (ctx->d_records) (void)hipFree(ctx->d_records);
     if (ctx->d_trace) (void)hipFree(ctx->d_trace);
