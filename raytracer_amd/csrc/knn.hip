@@ -59,25 +59,36 @@ __device__ __forceinline__ float knn_pair(const f2v (&qv)[8], const f2v *__restr
 // followed by what the RTL leaves to its consumer (IOSpec.scala:21-23): score = dot / sqrt(norm), both
 // correctly rounded.  Returned negated, and -0 as +0, so that "larger score first" is the ascending order
 // of the list code; a zero or NaN norm gives NaN, which no compare lets in.
-__device__ __forceinline__ void knn_dot_norm(const f2v (&qv)[8], const f2v *__restrict__ p, float &dot, float &norm) {
-    dot = 0.0f;
-    norm = 0.0f;
+__device__ __forceinline__ float knn_dot(const f2v (&qv)[8], const f2v *__restrict__ p) {
+    float dot = 0.0f;
 #pragma unroll
     for (int beat = 0; beat < 2; ++beat) {
-        f2v s[4], m[4];
+        f2v s[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const f2v c = p[beat * 4 + k];
-            s[k] = qv[beat * 4 + k] * c;
-            m[k] = c * c;
-        }
+        for (int k = 0; k < 4; ++k) s[k] = qv[beat * 4 + k] * p[beat * 4 + k];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) { s[k] = s[k] + s[k + 2]; m[k] = m[k] + m[k + 2]; }  // element i with i + 4
-        s[0] = s[0] + s[1];                                                               // i with i + 2
-        m[0] = m[0] + m[1];
+        for (int k = 0; k < 2; ++k) s[k] = s[k] + s[k + 2];  // element i with i + 4
+        s[0] = s[0] + s[1];                                   // i with i + 2
         dot = dot + (s[0].x + s[0].y);
+    }
+    return dot;
+}
+
+// The norm half of the same two beats.  It depends on the candidate alone, so the search computes it once per
+// point (one lane per point, 64 points at a time) and hands it to the wave by lane reads.
+__device__ __forceinline__ float knn_norm(const f2v (&c)[8]) {
+    float norm = 0.0f;
+#pragma unroll
+    for (int beat = 0; beat < 2; ++beat) {
+        f2v m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = c[beat * 4 + k] * c[beat * 4 + k];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) m[k] = m[k] + m[k + 2];
+        m[0] = m[0] + m[1];
         norm = norm + (m[0].x + m[0].y);
     }
+    return norm;
 }
 
 __device__ __forceinline__ float knn_neg_score(float dot, float norm) {
@@ -127,11 +138,15 @@ __device__ __forceinline__ void knn_offer(float (&bd)[kTopK], uint32_t (&bi)[kTo
 // 2^-19 (relative, plus 1e-30 absolute) of the bound, or when norm is so small that the estimate's input may have been flushed.
 // The examined pairs then go through knn_offer with their exact keys, so the lists hold exact keys only.
 __device__ __forceinline__ void knn_offer_angular(float (&bd)[kTopK], uint32_t (&bi)[kTopK], float &pd, uint32_t &pi, float &thr, float dot,
-                                                  float norm, uint32_t idx) {
-    const float est = -(dot * __builtin_amdgcn_rsqf(norm));
+                                                  float norm, float rsq_norm, uint32_t idx) {
+    const float est = -(dot * rsq_norm);
     const float slack = (fabsf(est) + fabsf(thr)) * 1.9073486328125e-06f + 1.0e-30f;  // 2^-19 relative; absolute where the product underflows
     const bool maybe = (norm < 1.0e-30f) || (est <= thr + slack);
     if (__any(maybe)) knn_offer(bd, bi, pd, pi, thr, maybe ? knn_neg_score(dot, norm) : __uint_as_float(0x7FC00000u), idx);
+}
+
+__device__ __forceinline__ float lane_read(float v, uint32_t lane) {  // lane is wave-uniform
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)lane));
 }
 
 constexpr int kKnnUnroll = 4;  // points per loop trip: their scalar loads are issued together
@@ -157,30 +172,44 @@ __global__ __launch_bounds__(256) void k_knn_euclid16(const float *__restrict__ 
 
     const uint32_t j0 = blockIdx.y * pts_per_split;
     const uint32_t j1 = (j0 + pts_per_split < n_pts) ? j0 + pts_per_split : n_pts;
-    uint32_t j = j0;
-    for (; j + kKnnUnroll <= j1; j += kKnnUnroll) {
-        const f2v *p = reinterpret_cast<const f2v *>(pts) + (size_t)j * 8;  // wave-uniform address
-        if (ANG) {
-            float dot[kKnnUnroll], norm[kKnnUnroll];
+    if (ANG) {
+        const uint32_t lane = threadIdx.x & 63u;
+        for (uint32_t jb = j0; jb < j1; jb += 64u) {
+            const uint32_t cnt = (j1 - jb < 64u) ? (j1 - jb) : 64u;
+            // this lane's point of the block: its norm and the reciprocal square root estimate of the filter
+            const f2v *mine = reinterpret_cast<const f2v *>(pts) + (size_t)(jb + (lane < cnt ? lane : cnt - 1u)) * 8;
+            f2v c[8];
 #pragma unroll
-            for (int u = 0; u < kKnnUnroll; ++u) knn_dot_norm(qv, p + u * 8, dot[u], norm[u]);
+            for (int k = 0; k < 8; ++k) c[k] = mine[k];
+            const float my_norm = knn_norm(c);
+            const float my_rsq = __builtin_amdgcn_rsqf(my_norm);
+            uint32_t u = 0;
+            for (; u + kKnnUnroll <= cnt; u += kKnnUnroll) {
+                const f2v *p = reinterpret_cast<const f2v *>(pts) + (size_t)(jb + u) * 8;  // wave-uniform address
+                float dot[kKnnUnroll];
 #pragma unroll
-            for (int u = 0; u < kKnnUnroll; ++u) knn_offer_angular(bd, bi, pd, pi, thr, dot[u], norm[u], idx_base + j + u);
-        } else {
+                for (int v = 0; v < kKnnUnroll; ++v) dot[v] = knn_dot(qv, p + v * 8);
+#pragma unroll
+                for (int v = 0; v < kKnnUnroll; ++v)
+                    knn_offer_angular(bd, bi, pd, pi, thr, dot[v], lane_read(my_norm, u + v), lane_read(my_rsq, u + v), idx_base + jb + u + v);
+            }
+            for (; u < cnt; ++u) {
+                const f2v *p = reinterpret_cast<const f2v *>(pts) + (size_t)(jb + u) * 8;
+                knn_offer_angular(bd, bi, pd, pi, thr, knn_dot(qv, p), lane_read(my_norm, u), lane_read(my_rsq, u), idx_base + jb + u);
+            }
+        }
+    } else {
+        uint32_t j = j0;
+        for (; j + kKnnUnroll <= j1; j += kKnnUnroll) {
+            const f2v *p = reinterpret_cast<const f2v *>(pts) + (size_t)j * 8;  // wave-uniform address
             float dist[kKnnUnroll];
 #pragma unroll
             for (int u = 0; u < kKnnUnroll; ++u) dist[u] = knn_pair(qv, p + u * 8);
 #pragma unroll
             for (int u = 0; u < kKnnUnroll; ++u) knn_offer(bd, bi, pd, pi, thr, dist[u], idx_base + j + u);
         }
-    }
-    for (; j < j1; ++j) {
-        const f2v *p = reinterpret_cast<const f2v *>(pts) + (size_t)j * 8;
-        if (ANG) {
-            float dot, norm;
-            knn_dot_norm(qv, p, dot, norm);
-            knn_offer_angular(bd, bi, pd, pi, thr, dot, norm, idx_base + j);
-        } else {
+        for (; j < j1; ++j) {
+            const f2v *p = reinterpret_cast<const f2v *>(pts) + (size_t)j * 8;
             knn_offer(bd, bi, pd, pi, thr, knn_pair(qv, p), idx_base + j);
         }
     }
