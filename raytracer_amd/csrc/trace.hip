@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void k_trace_tri(const uint2 *__restrict__ lea
 //   node: Quadbox op with extent = limit; push the hit children in reverse sorted order.
 // A ray's walk is sequential, so the result is deterministic by construction.
 constexpr int kStackDepth = 64;
+constexpr int kStackLds = 8;  // the top-of-stack entries that live in LDS ([entry][thread]: conflict-free); deeper ones in scratch
 
 __global__ __launch_bounds__(256) void k_trace_dfs(const float *ox, const float *oy, const float *oz, const float *dx, const float *dy,
                                                    const float *dz, uint32_t n, float extent, const float *__restrict__ nodes,
@@ -206,9 +207,19 @@ __global__ __launch_bounds__(256) void k_trace_dfs(const float *ox, const float 
 #pragma unroll
     for (int c = 0; c < 3; ++c) { r[3 + c] = d[c]; r[6 + c] = inv[c]; }
 
-    uint2 stack[kStackDepth];  // (reference, bits of the entry distance)
+    __shared__ uint2 s_stack[kStackLds][256];
+    uint2 deep[kStackDepth - kStackLds];  // (reference, bits of the entry distance)
     int sp = 0;
-    if (live) stack[sp++] = uint2{0u, 0u};  // the root, entry distance +0
+    auto push = [&](uint2 e) {
+        if (sp < kStackLds) s_stack[sp][threadIdx.x] = e;
+        else deep[sp - kStackLds] = e;
+        ++sp;
+    };
+    auto pop = [&]() -> uint2 {
+        --sp;
+        return (sp < kStackLds) ? s_stack[sp][threadIdx.x] : deep[sp - kStackLds];
+    };
+    if (live) push(uint2{0u, 0u});  // the root, entry distance +0
     unsigned long long best = kBestNone;
     uint32_t n_box = 0, n_tri = 0;
     bool spilled = false;
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(256) void k_trace_dfs(const float *ox, const float 
         uint32_t ref = kRefNone;
         float limit = 0.0f;
         if (sp > 0) {
-            const uint2 e = stack[--sp];
+            const uint2 e = pop();
             const float found = __uint_as_float((uint32_t)(best >> 32));
             limit = (found < extent) ? found : extent;
             if (__uint_as_float(e.y) < limit) ref = e.x;
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(256) void k_trace_dfs(const float *ox, const float 
                 const uint32_t slot = (flags >> (4 + 2 * k)) & 3u;
                 const uint32_t c = (slot == 0u) ? child.x : (slot == 1u) ? child.y : (slot == 2u) ? child.z : child.w;
                 if (((flags >> k) & 1u) && c != kRefNone) {
-                    if (sp < kStackDepth) stack[sp++] = uint2{c, __float_as_uint(t[k])};
+                    if (sp < kStackDepth) push(uint2{c, __float_as_uint(t[k])});
                     else spilled = true;
                 }
             }
