@@ -902,10 +902,10 @@ int rt_dp_trace_closest(rt_dp_ctx *ctx, const rt_dp_bvh4 *bvh, const float *cons
             return fail(RT_DP_EINVAL, "node %u holds a child reference outside the hierarchy (inner children must have a larger index than their parent)", bad - 1);
     }
     if (!wavefront) {
-        unsigned long long *totals = reinterpret_cast<unsigned long long *>(counters);  // [0] box ops, [1] triangle ops, then the overflow flag
+        unsigned long long *totals = reinterpret_cast<unsigned long long *>(counters);  // [0] box ops, [1] triangle ops, [2] the overflow flag, [3] the ray counter
         uint32_t *overflow = counters + 4;
         HIP_TRY(hipMemsetAsync(counters, 0, 32, s));
-        HIP_TRY(trace_dfs(origin, dir, n_rays, extent, bvh->nodes, bvh->tris, out_t, out_tri, totals, overflow, s));
+        HIP_TRY(trace_dfs(origin, dir, n_rays, extent, bvh->nodes, bvh->tris, out_t, out_tri, totals, overflow, totals + 3, s));
         unsigned long long host[3];
         HIP_TRY(hipMemcpyAsync(host, counters, 24, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));

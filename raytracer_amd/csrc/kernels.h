@@ -96,7 +96,8 @@ hipError_t trace_box(const void *cur, uint32_t count, const float *rays, const f
 hipError_t trace_tri(const void *leaf, uint32_t count, const float *rays, const float *tris, unsigned long long *best, uint32_t *counters,
                      hipStream_t s);
 hipError_t trace_dfs(const float *const origin[3], const float *const dir[3], uint32_t n, float extent, const float *nodes, const float *tris,
-                     float *out_t, uint32_t *out_tri, unsigned long long *totals, uint32_t *overflow, hipStream_t s);
+                     float *out_t, uint32_t *out_tri, unsigned long long *totals, uint32_t *overflow, unsigned long long *next /* zeroed */,
+                     hipStream_t s);
 hipError_t trace_finish(const unsigned long long *best, uint32_t n, float *out_t, uint32_t *out_tri, hipStream_t s);
 hipError_t launch_knn_tree16(const float *pts, const uint32_t *index, const float *leaf_lo, const float *leaf_hi, uint32_t n_leaves,
                              uint32_t leaf_size, const float *qry, const uint32_t *home, uint32_t n_qry, uint32_t log2_splits, uint32_t walk,

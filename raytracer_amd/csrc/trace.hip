@@ -191,21 +191,21 @@ __global__ __launch_bounds__(256) void k_trace_tri(const uint2 *__restrict__ lea
 constexpr int kStackDepth = 64;
 constexpr int kStackLds = 8;  // the top-of-stack entries that live in LDS ([entry][thread]: conflict-free); deeper ones in scratch
 
+constexpr int kRefillLanes = 32;  // a wave fetches new rays once this many of its lanes have finished theirs
+
+// Persistent form: the grid holds as many waves as the chip keeps resident; a lane that finished its ray takes
+// another from a global counter (whole-wave refills, so the divergent set-up is paid rarely).  Which lane walks
+// which ray is scheduling-dependent; what a ray's walk computes is not.
 __global__ __launch_bounds__(256) void k_trace_dfs(const float *ox, const float *oy, const float *oz, const float *dx, const float *dy,
                                                    const float *dz, uint32_t n, float extent, const float *__restrict__ nodes,
                                                    const float *__restrict__ tris, float *__restrict__ out_t, uint32_t *__restrict__ out_tri,
-                                                   unsigned long long *__restrict__ totals, uint32_t *__restrict__ overflow) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const bool live = i < n;
-    const uint32_t ii = live ? i : n - 1;
-    float r[kBoxFields];
-    r[0] = ox[ii]; r[1] = oy[ii]; r[2] = oz[ii];
-    const float d[3] = {dx[ii], dy[ii], dz[ii]};
-    float inv[3], shear[3];
-    uint32_t kw;
-    ray_derive(d, inv, kw, shear);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { r[3 + c] = d[c]; r[6 + c] = inv[c]; }
+                                                   unsigned long long *__restrict__ totals, uint32_t *__restrict__ overflow,
+                                                   unsigned long long *__restrict__ next) {
+    constexpr uint32_t kNoRay = 0xFFFFFFFFu;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lanes_total = (unsigned long long)gridDim.x * 256u;
+    float r[kBoxFields], shear[3];
+    uint32_t kw = 0;
 
     __shared__ uint2 s_stack[kStackLds][256];
     uint2 deep[kStackDepth - kStackLds];  // (reference, bits of the entry distance)
@@ -219,15 +219,53 @@ __global__ __launch_bounds__(256) void k_trace_dfs(const float *ox, const float 
         --sp;
         return (sp < kStackLds) ? s_stack[sp][threadIdx.x] : deep[sp - kStackLds];
     };
-    if (live) push(uint2{0u, 0u});  // the root, entry distance +0
+    uint32_t ray = kNoRay;
     unsigned long long best = kBestNone;
+    auto take = [&](uint32_t id) {
+        r[0] = ox[id]; r[1] = oy[id]; r[2] = oz[id];
+        const float d[3] = {dx[id], dy[id], dz[id]};
+        float inv[3];
+        ray_derive(d, inv, kw, shear);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { r[3 + c] = d[c]; r[6 + c] = inv[c]; }
+        ray = id;
+        best = kBestNone;
+        sp = 0;
+        push(uint2{0u, 0u});  // the root, entry distance +0
+    };
+    {
+        const unsigned long long first = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+        if (first < n) take((uint32_t)first);
+    }
+    bool exhausted = lanes_total >= n;  // wave-uniform: no ray left behind the counter
     uint32_t n_box = 0, n_tri = 0;
     bool spilled = false;
 
-    while (__any(sp > 0)) {
+    for (;;) {
+        if (ray != kNoRay && sp == 0) {  // this lane's ray is done
+            out_t[ray] = __uint_as_float((uint32_t)(best >> 32));
+            out_tri[ray] = (uint32_t)best;
+            ray = kNoRay;
+        }
+        const unsigned long long idle = __ballot(ray == kNoRay);
+        if (idle) {
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (!exhausted && n_idle >= (uint32_t)kRefillLanes) {
+                const int leader = __ffsll((long long)idle) - 1;
+                unsigned long long base = 0;
+                if ((int)lane == leader) base = atomicAdd(next, (unsigned long long)n_idle);
+                base = __shfl(base, leader) + lanes_total;
+                if (ray == kNoRay) {
+                    const unsigned long long id = base + (unsigned long long)__popcll(idle & ((1ull << lane) - 1ull));
+                    if (id < n) take((uint32_t)id);
+                }
+                exhausted = base + n_idle >= n;
+            }
+            if (!__any(ray != kNoRay)) break;  // every lane idle and nothing left to fetch
+        }
         uint32_t ref = kRefNone;
         float limit = 0.0f;
-        if (sp > 0) {
+        if (ray != kNoRay) {
             const uint2 e = pop();
             const float found = __uint_as_float((uint32_t)(best >> 32));
             limit = (found < extent) ? found : extent;
@@ -278,11 +316,7 @@ __global__ __launch_bounds__(256) void k_trace_dfs(const float *ox, const float 
             n_tri += cnt;
         }
     }
-    if (live) {
-        out_t[i] = __uint_as_float((uint32_t)(best >> 32));
-        out_tri[i] = (uint32_t)best;
-        if (spilled) atomicOr(overflow, 1u);
-    }
+    if (spilled) atomicOr(overflow, 1u);
     // statistics: one atomic pair per wave
     for (int off = 32; off > 0; off >>= 1) {
         n_box += __shfl_down(n_box, off);
@@ -330,9 +364,10 @@ hipError_t trace_tri(const void *leaf, uint32_t count, const float *rays, const 
 }
 
 hipError_t trace_dfs(const float *const origin[3], const float *const dir[3], uint32_t n, float extent, const float *nodes, const float *tris,
-                     float *out_t, uint32_t *out_tri, unsigned long long *totals, uint32_t *overflow, hipStream_t s) {
-    hipLaunchKernelGGL(k_trace_dfs, dim3((n + 255) / 256), dim3(256), 0, s, origin[0], origin[1], origin[2], dir[0], dir[1], dir[2], n, extent,
-                       nodes, tris, out_t, out_tri, totals, overflow);
+                     float *out_t, uint32_t *out_tri, unsigned long long *totals, uint32_t *overflow, unsigned long long *next, hipStream_t s) {
+    const uint32_t need = (n + 255) / 256, resident = 256u * 8u;  // 8 workgroups of 4 waves per CU stay resident
+    hipLaunchKernelGGL(k_trace_dfs, dim3(need < resident ? need : resident), dim3(256), 0, s, origin[0], origin[1], origin[2], dir[0], dir[1],
+                       dir[2], n, extent, nodes, tris, out_t, out_tri, totals, overflow, next);
     return hipGetLastError();
 }
 
