@@ -133,16 +133,23 @@ __device__ __forceinline__ void knn_offer(float (&bd)[kTopK], uint32_t (&bi)[kTo
 }
 
 // The angular search's offer.  The exact key -RN(dot / RN(sqrt(norm))) costs two correctly rounded
-// operations; almost every pair is turned away first by -dot * rsq(norm) (v_rsq_f32, 1 ulp), whose relative
-// distance from the exact key is below 2^-21: a pair is examined exactly when the estimate is within
-// 2^-19 (relative, plus 1e-30 absolute) of the bound, or when norm is so small that the estimate's input may have been flushed.
-// The examined pairs then go through knn_offer with their exact keys, so the lists hold exact keys only.
-__device__ __forceinline__ void knn_offer_angular(float (&bd)[kTopK], uint32_t (&bi)[kTopK], float &pd, uint32_t &pi, float &thr, float dot,
-                                                  float norm, float rsq_norm, uint32_t idx) {
+// operations; almost every pair is turned away first by the estimate est = -dot * rsq(norm) (v_rsq_f32, 1 ulp),
+// whose relative distance from the exact key is below 2^-21.  A pair is examined unless
+//     est - |est| 2^-19  >  gate,   gate = thr + |thr| 2^-19 + 1e-30
+// (the margins widen both sides by 2^-19 relative, the absolute term covers products that underflow), written
+// as a negated "greater than" so that a NaN estimate is examined too; rsq_norm arrives as NaN for a point whose
+// norm is so small that the estimate's input may have been flushed.  The examined pairs go through knn_offer
+// with their exact keys, so the lists hold exact keys only.  `gate` follows thr, which only knn_offer changes.
+__device__ __forceinline__ float knn_gate(float thr) { return thr + fabsf(thr) * 1.9073486328125e-06f + 1.0e-30f; }
+
+__device__ __forceinline__ void knn_offer_angular(float (&bd)[kTopK], uint32_t (&bi)[kTopK], float &pd, uint32_t &pi, float &thr, float &gate,
+                                                  float dot, float norm, float rsq_norm, uint32_t idx) {
     const float est = -(dot * rsq_norm);
-    const float slack = (fabsf(est) + fabsf(thr)) * 1.9073486328125e-06f + 1.0e-30f;  // 2^-19 relative; absolute where the product underflows
-    const bool maybe = (norm < 1.0e-30f) || (est <= thr + slack);
-    if (__any(maybe)) knn_offer(bd, bi, pd, pi, thr, maybe ? knn_neg_score(dot, norm) : __uint_as_float(0x7FC00000u), idx);
+    const bool maybe = !(est - fabsf(est) * 1.9073486328125e-06f > gate);
+    if (__any(maybe)) {
+        knn_offer(bd, bi, pd, pi, thr, maybe ? knn_neg_score(dot, norm) : __uint_as_float(0x7FC00000u), idx);
+        gate = knn_gate(thr);
+    }
 }
 
 __device__ __forceinline__ float lane_read(float v, uint32_t lane) {  // lane is wave-uniform
@@ -174,6 +181,7 @@ __global__ __launch_bounds__(256) void k_knn_euclid16(const float *__restrict__ 
     const uint32_t j1 = (j0 + pts_per_split < n_pts) ? j0 + pts_per_split : n_pts;
     if (ANG) {
         const uint32_t lane = threadIdx.x & 63u;
+        float gate = knn_gate(thr);
         for (uint32_t jb = j0; jb < j1; jb += 64u) {
             const uint32_t cnt = (j1 - jb < 64u) ? (j1 - jb) : 64u;
             // this lane's point of the block: its norm and the reciprocal square root estimate of the filter
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(256) void k_knn_euclid16(const float *__restrict__ 
 #pragma unroll
             for (int k = 0; k < 8; ++k) c[k] = mine[k];
             const float my_norm = knn_norm(c);
-            const float my_rsq = __builtin_amdgcn_rsqf(my_norm);
+            const float my_rsq = (my_norm < 1.0e-30f) ? __uint_as_float(0x7FC00000u) : __builtin_amdgcn_rsqf(my_norm);
             uint32_t u = 0;
             for (; u + kKnnUnroll <= cnt; u += kKnnUnroll) {
                 const f2v *p = reinterpret_cast<const f2v *>(pts) + (size_t)(jb + u) * 8;  // wave-uniform address
@@ -191,11 +199,11 @@ __global__ __launch_bounds__(256) void k_knn_euclid16(const float *__restrict__ 
                 for (int v = 0; v < kKnnUnroll; ++v) dot[v] = knn_dot(qv, p + v * 8);
 #pragma unroll
                 for (int v = 0; v < kKnnUnroll; ++v)
-                    knn_offer_angular(bd, bi, pd, pi, thr, dot[v], lane_read(my_norm, u + v), lane_read(my_rsq, u + v), idx_base + jb + u + v);
+                    knn_offer_angular(bd, bi, pd, pi, thr, gate, dot[v], lane_read(my_norm, u + v), lane_read(my_rsq, u + v), idx_base + jb + u + v);
             }
             for (; u < cnt; ++u) {
                 const f2v *p = reinterpret_cast<const f2v *>(pts) + (size_t)(jb + u) * 8;
-                knn_offer_angular(bd, bi, pd, pi, thr, knn_dot(qv, p), lane_read(my_norm, u), lane_read(my_rsq, u), idx_base + jb + u);
+                knn_offer_angular(bd, bi, pd, pi, thr, gate, knn_dot(qv, p), lane_read(my_norm, u), lane_read(my_rsq, u), idx_base + jb + u);
             }
         }
     } else {
