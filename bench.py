@@ -55,6 +55,7 @@ def parse():
     p.add_argument("--vec-tile", type=int, default=0)
     p.add_argument("--variant", type=int, default=0)
     p.add_argument("--vec-passes", type=int, default=0)
+    p.add_argument("--wgs-per-cu", type=int, default=0, help="resident workgroups per CU of the op kernels: 0 library default, 3..16, 99 no cap")
     p.add_argument("--only", default="", help="restrict to one workload: box|tri|euclid|angular|mixed")
     # tuning: 0 = library default; nontemporal 1 = on, 2 = off
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -472,6 +473,7 @@ def main():
     which = [a.only] if a.only else ["box", "tri", "euclid", "angular", "mixed"]
     ctx = capi.Context(device=local)
     ctx.set_tuning(a.ops_per_lane, a.nontemporal, a.vec_tile, a.variant, a.vec_passes)
+    ctx.set_option("wgs_per_cu", a.wgs_per_cu)
     if a.derive:
         BYTES.update(box=144, tri=72)
     batches = make_batches(n, dev, which, a.stagger_kib, bool(a.derive))
@@ -502,7 +504,7 @@ def main():
         "config": {"workload": "%s: %s random ray-vs-4-AABB box ops per GPU, SoA fp32 operands resident in HBM" % (head, size_text)
                    if head == "box" else "%s, %s units per GPU" % (head, size_text),
                    "ops_per_gpu": r["units_per_gpu"], "bytes_per_op": BYTES.get(head), "sharding": "independent op streams per GPU, no collective",
-                   "tuning": {"ops_per_lane": a.ops_per_lane, "nontemporal": a.nontemporal, "vec_tile": a.vec_tile, "variant": a.variant, "vec_passes": a.vec_passes, "derive": a.derive}},
+                   "tuning": {"ops_per_lane": a.ops_per_lane, "nontemporal": a.nontemporal, "vec_tile": a.vec_tile, "variant": a.variant, "vec_passes": a.vec_passes, "derive": a.derive, "wgs_per_cu": a.wgs_per_cu}},
         "roofline": r["roofline"],
     }
     if rank == 0:

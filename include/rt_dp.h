@@ -455,7 +455,9 @@ int rt_dp_set_tuning(rt_dp_ctx *ctx, int ops_per_lane, int nontemporal, int vec_
 /* Further integer knobs by name: "vec_passes" (opcodes 2/3: 16-byte load pairs in flight per
  * lane and sub-tile, 2 / 4 / 8), "variant" (0 normal; 10 diagnostic: the box kernel's memory
  * pattern without its arithmetic, outputs meaningless).  Environment: RT_DP_VEC_PASSES,
- * RT_DP_VARIANT.  "stream_mode" selects how rt_dp_eval_bundles_device works: 1 partitions the
+ * RT_DP_VARIANT.  "wgs_per_cu" (resident 256-thread workgroups per CU of the box / triangle / beat
+ * kernels: 0 the measured per-kernel default, 3..16, 99 as many as fit; environment RT_DP_WGS_PER_CU).
+ * "stream_mode" selects how rt_dp_eval_bundles_device works: 1 partitions the
  * records by opcode into structure-of-arrays segments first, 2 evaluates them in place in one
  * pass (needs 16-byte aligned record arrays), 0 (default) picks 2 when the alignment allows. */
 int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value);

@@ -66,7 +66,7 @@ struct rt_dp_ctx {
     // leaf-major k-NN: per-query / per-leaf tables, the (leaf, query) lists, the candidate slots
     char *d_knn[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t knn_bytes[4] = {0, 0, 0, 0};
-    Tuning tuning{0, 0, 0, 0, 0};
+    Tuning tuning{0, 0, 0, 0, 0, 0};
     int stream_mode = 0;  // record streams in HBM: 0 automatic, 1 partition by opcode first, 2 fused single pass
 };
 
@@ -360,6 +360,7 @@ int rt_dp_create(const rt_dp_config *cfg, rt_dp_ctx **out) {
     ctx->tuning.vec_tile = env_int("RT_DP_VEC_TILE", 0);
     ctx->tuning.variant = env_int("RT_DP_VARIANT", 0);
     ctx->tuning.vec_passes = env_int("RT_DP_VEC_PASSES", 0);
+    ctx->tuning.wgs_per_cu = env_int("RT_DP_WGS_PER_CU", 0);
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_state, 12 * sizeof(float));
     if (e == hipSuccess) e = hipMemsetAsync(ctx->d_state, 0, 12 * sizeof(float), ctx->stream);
@@ -970,6 +971,9 @@ int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value) {
     if (!strcmp(key, "variant")) {
         if (!(value == 0 || value == 10)) return fail(RT_DP_EINVAL, "variant must be 0 or 10 (diagnostic)");
         ctx->tuning.variant = value;
+    } else if (!strcmp(key, "wgs_per_cu")) {
+        if (!(value == 0 || value == 99 || (value >= 3 && value <= 16))) return fail(RT_DP_EINVAL, "wgs_per_cu must be 0 (default), 3..16, or 99 (no cap)");
+        ctx->tuning.wgs_per_cu = value;
     } else if (!strcmp(key, "stream_mode")) {
         if (value < 0 || value > 2) return fail(RT_DP_EINVAL, "stream_mode must be 0 (automatic), 1 (partition) or 2 (fused)");
         ctx->stream_mode = value;

@@ -49,6 +49,7 @@ struct Tuning {
     int vec_tile;      // Euclidean / angular: nominal beats per workgroup
     int variant;       // 0 normal; 10 diagnostic: the box kernel's memory pattern without its arithmetic
     int vec_passes;    // Euclidean / angular: 16-byte load pairs in flight per lane and sub-tile (2, 4 or 8)
+    int wgs_per_cu;    // resident workgroups per CU of the op kernels: 0 per-kernel default, 1..16 that many, 99 whatever fits
 };
 
 hipError_t launch_box(const BoxArgs &args, uint64_t n, const Tuning &t, hipStream_t stream, bool derive = false);  // derive: in[6..8] unused

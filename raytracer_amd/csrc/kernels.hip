@@ -414,40 +414,58 @@ static inline int min_align(const void *const *ptrs, int count) {
     return 4;
 }
 
-#define RTDP_LAUNCH_OPS(KERNEL, ARGS, N, V, NT, STREAM)                                               \
+// Residency cap.  These kernels stream: once the bytes in flight cover latency x bandwidth, more resident waves
+// only lengthen the queues in front of the memory channels and scatter the DRAM page hits (measured: the box
+// kernel at 2^24 ops runs at 0.765 of the HBM peak with the 7 workgroups per CU its registers allow, 0.82 with
+// 3).  A launch states how many 256-thread workgroups a CU may hold by asking for that share of the CU's 160 KiB
+// of LDS as dynamic shared memory, which the kernel never touches.
+constexpr int kBoxWgsPerCu = 3, kTriWgsPerCu = 5, kVecWgsPerCu = 99;  // from sweeps on MI355X
+
+static unsigned residency_lds(int wgs, int dflt, unsigned static_lds) {
+    int w = (wgs > 0) ? wgs : dflt;
+    if (w >= 99 || w <= 0) return 0u;
+    if (w < 3) w = 3;  // more than 64 KiB of dynamic LDS per workgroup would need a function attribute
+    if (w > 16) return 0u;
+    // gfx950 hands out LDS in granules of 1280 bytes, 128 of them per CU (measured: the plateaus of the
+    // kernel time against the requested size end at 20480, 23040, 26880, 32000, 40960 and 53760 bytes)
+    const unsigned share = (128u / (unsigned)w) * 1280u;  // w shares fit, w + 1 do not
+    return share > static_lds ? share - static_lds : 0u;
+}
+
+#define RTDP_LAUNCH_OPS(KERNEL, ARGS, FIRST, N, V, NT, STREAM, LDS)                                             \
     do {                                                                                              \
         const uint64_t groups_ = (N) / (V);                                                           \
         if (groups_) {                                                                                \
             const uint64_t blocks_ = (groups_ + 255) / 256;                                           \
-            hipLaunchKernelGGL((KERNEL<V, NT>), dim3((unsigned)blocks_), dim3(256), 0, STREAM, ARGS,  \
-                               (uint64_t)0, groups_);                                                 \
+            hipLaunchKernelGGL((KERNEL<V, NT>), dim3((unsigned)blocks_), dim3(256), LDS, STREAM, ARGS, \
+                               (uint64_t)(FIRST), groups_);                                           \
         }                                                                                             \
         const uint64_t tail_ = (N) - groups_ * (V);                                                   \
         if ((V) > 1 && tail_) {                                                                       \
-            hipLaunchKernelGGL((KERNEL<1, NT>), dim3(1), dim3(256), 0, STREAM, ARGS, groups_ * (V),   \
+            hipLaunchKernelGGL((KERNEL<1, NT>), dim3(1), dim3(256), 0, STREAM, ARGS, (FIRST) + groups_ * (V), \
                                tail_);                                                                \
         }                                                                                             \
     } while (0)
 
-template <bool NT> static void launch_box_v(const BoxArgs &a, uint64_t n, int v, hipStream_t s) {
-    if (v == 4) RTDP_LAUNCH_OPS(k_box, a, n, 4, NT, s);
-    else if (v == 2) RTDP_LAUNCH_OPS(k_box, a, n, 2, NT, s);
-    else RTDP_LAUNCH_OPS(k_box, a, n, 1, NT, s);
+template <bool NT> static void launch_box_v(const BoxArgs &a, uint64_t first, uint64_t n, int v, unsigned lds, hipStream_t s) {
+    if (v == 4) RTDP_LAUNCH_OPS(k_box, a, first, n, 4, NT, s, lds);
+    else if (v == 2) RTDP_LAUNCH_OPS(k_box, a, first, n, 2, NT, s, lds);
+    else RTDP_LAUNCH_OPS(k_box, a, first, n, 1, NT, s, lds);
 }
-template <bool NT> static void launch_tri_v(const TriArgs &a, uint64_t n, int v, hipStream_t s) {
-    if (v == 4) RTDP_LAUNCH_OPS(k_tri, a, n, 4, NT, s);
-    else if (v == 2) RTDP_LAUNCH_OPS(k_tri, a, n, 2, NT, s);
-    else RTDP_LAUNCH_OPS(k_tri, a, n, 1, NT, s);
+template <bool NT> static void launch_tri_v(const TriArgs &a, uint64_t first, uint64_t n, int v, unsigned lds, hipStream_t s) {
+    if (v == 4) RTDP_LAUNCH_OPS(k_tri, a, first, n, 4, NT, s, lds);
+    else if (v == 2) RTDP_LAUNCH_OPS(k_tri, a, first, n, 2, NT, s, lds);
+    else RTDP_LAUNCH_OPS(k_tri, a, first, n, 1, NT, s, lds);
 }
-template <bool NT> static void launch_box_derive_v(const BoxArgs &a, uint64_t n, int v, hipStream_t s) {
-    if (v == 4) RTDP_LAUNCH_OPS(k_box_derive, a, n, 4, NT, s);
-    else if (v == 2) RTDP_LAUNCH_OPS(k_box_derive, a, n, 2, NT, s);
-    else RTDP_LAUNCH_OPS(k_box_derive, a, n, 1, NT, s);
+template <bool NT> static void launch_box_derive_v(const BoxArgs &a, uint64_t first, uint64_t n, int v, unsigned lds, hipStream_t s) {
+    if (v == 4) RTDP_LAUNCH_OPS(k_box_derive, a, first, n, 4, NT, s, lds);
+    else if (v == 2) RTDP_LAUNCH_OPS(k_box_derive, a, first, n, 2, NT, s, lds);
+    else RTDP_LAUNCH_OPS(k_box_derive, a, first, n, 1, NT, s, lds);
 }
-template <bool NT> static void launch_tri_derive_v(const TriArgs &a, uint64_t n, int v, hipStream_t s) {
-    if (v == 4) RTDP_LAUNCH_OPS(k_tri_derive, a, n, 4, NT, s);
-    else if (v == 2) RTDP_LAUNCH_OPS(k_tri_derive, a, n, 2, NT, s);
-    else RTDP_LAUNCH_OPS(k_tri_derive, a, n, 1, NT, s);
+template <bool NT> static void launch_tri_derive_v(const TriArgs &a, uint64_t first, uint64_t n, int v, unsigned lds, hipStream_t s) {
+    if (v == 4) RTDP_LAUNCH_OPS(k_tri_derive, a, first, n, 4, NT, s, lds);
+    else if (v == 2) RTDP_LAUNCH_OPS(k_tri_derive, a, first, n, 2, NT, s, lds);
+    else RTDP_LAUNCH_OPS(k_tri_derive, a, first, n, 1, NT, s, lds);
 }
 
 // Operand and result streams are touched exactly once, so by default they carry the
@@ -472,13 +490,13 @@ hipError_t launch_box(const BoxArgs &args, uint64_t n, const Tuning &t, hipStrea
     for (int i = 0; i < kBoxFields; ++i) ptrs[i] = (derive && i >= 6 && i <= 8) ? nullptr : args.in[i];
     for (int i = 0; i < 4; ++i) ptrs[kBoxFields + i] = args.tmin[i];
     ptrs[kBoxFields + 4] = args.flags;
-    // measured: below 2^23 ops one op per lane (twice the workgroups) fills the chip better; above, two ops per lane win
-    const int v = pick_v(t.ops_per_lane, min_align(ptrs, kBoxFields + 5), n < (uint64_t(1) << 23) ? 1 : 2);
+    const int v = pick_v(t.ops_per_lane, min_align(ptrs, kBoxFields + 5), 1);  // measured with the residency cap: 1 beats 2 and 4 from 2^20 to 2^25 ops
+    const unsigned lds = residency_lds(t.wgs_per_cu, n >= (uint64_t(1) << 20) ? kBoxWgsPerCu : 99, 0u);
     if (derive) {
-        if (use_nt(t)) launch_box_derive_v<true>(args, n, v, stream);
-        else launch_box_derive_v<false>(args, n, v, stream);
-    } else if (use_nt(t)) launch_box_v<true>(args, n, v, stream);
-    else launch_box_v<false>(args, n, v, stream);
+        if (use_nt(t)) launch_box_derive_v<true>(args, 0, n, v, lds, stream);
+        else launch_box_derive_v<false>(args, 0, n, v, lds, stream);
+    } else if (use_nt(t)) launch_box_v<true>(args, 0, n, v, lds, stream);
+    else launch_box_v<false>(args, 0, n, v, lds, stream);
     return hipGetLastError();
 }
 
@@ -491,19 +509,21 @@ hipError_t launch_tri(const TriArgs &args, uint64_t n, const Tuning &t, hipStrea
     ptrs[kTriFields + 2] = args.t_denom;
     ptrs[kTriFields + 3] = args.hit;
     const int v = pick_v(t.ops_per_lane, min_align(ptrs, kTriFields + 4), 1);  // measured: never slower than 2, 5-20 % faster below 2^24 ops
+    const unsigned lds = residency_lds(t.wgs_per_cu, n >= (uint64_t(1) << 21) ? kTriWgsPerCu : 99, 0u);
     if (derive) {
-        if (use_nt(t)) launch_tri_derive_v<true>(args, n, v, stream);
-        else launch_tri_derive_v<false>(args, n, v, stream);
-    } else if (use_nt(t)) launch_tri_v<true>(args, n, v, stream);
-    else launch_tri_v<false>(args, n, v, stream);
+        if (use_nt(t)) launch_tri_derive_v<true>(args, 0, n, v, lds, stream);
+        else launch_tri_derive_v<false>(args, 0, n, v, lds, stream);
+    } else if (use_nt(t)) launch_tri_v<true>(args, 0, n, v, lds, stream);
+    else launch_tri_v<false>(args, 0, n, v, lds, stream);
     return hipGetLastError();
 }
 
-template <bool EUC, bool NT> static void launch_vec_p(const VecArgs &args, uint64_t n, uint32_t tile, int passes, unsigned blocks, hipStream_t stream) {
+template <bool EUC, bool NT> static void launch_vec_p(const VecArgs &args, uint64_t n, uint32_t tile, int passes, unsigned blocks, unsigned lds,
+                                                      hipStream_t stream) {
     switch (passes) {
-    case 2: hipLaunchKernelGGL((k_vec<EUC, NT, 2>), dim3(blocks), dim3(kThreads), 0, stream, args, n, tile); break;
-    case 8: hipLaunchKernelGGL((k_vec<EUC, NT, 8>), dim3(blocks), dim3(kThreads), 0, stream, args, n, tile); break;
-    default: hipLaunchKernelGGL((k_vec<EUC, NT, 4>), dim3(blocks), dim3(kThreads), 0, stream, args, n, tile); break;
+    case 2: hipLaunchKernelGGL((k_vec<EUC, NT, 2>), dim3(blocks), dim3(kThreads), lds, stream, args, n, tile); break;
+    case 8: hipLaunchKernelGGL((k_vec<EUC, NT, 8>), dim3(blocks), dim3(kThreads), lds, stream, args, n, tile); break;
+    default: hipLaunchKernelGGL((k_vec<EUC, NT, 4>), dim3(blocks), dim3(kThreads), lds, stream, args, n, tile); break;
     }
 }
 
@@ -515,8 +535,9 @@ template <bool EUC> static hipError_t launch_vec(const VecArgs &args, uint64_t n
     if (tile < 64u) tile = 64u;
     const uint64_t blocks = (n + tile - 1) / tile;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if (use_nt(t)) launch_vec_p<EUC, true>(args, n, tile, passes, (unsigned)blocks, stream);
-    else launch_vec_p<EUC, false>(args, n, tile, passes, (unsigned)blocks, stream);
+    const unsigned lds = residency_lds(t.wgs_per_cu, kVecWgsPerCu, 8192u);  // the kernel's own LDS stays below 8 KiB
+    if (use_nt(t)) launch_vec_p<EUC, true>(args, n, tile, passes, (unsigned)blocks, lds, stream);
+    else launch_vec_p<EUC, false>(args, n, tile, passes, (unsigned)blocks, lds, stream);
     return hipGetLastError();
 }
 
