@@ -15,6 +15,8 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
+static unsigned g_lds = 0;  // dynamic LDS per workgroup, used only to limit residency
+
 template <typename T, bool NT, int STREAMS>
 __global__ __launch_bounds__(256) void k_read(const T *const in, T *sink, size_t n_per_stream) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -109,21 +111,21 @@ template <typename F> static double time_ms(F launch, int reps = 7) {
 template <typename T, bool NT, int STREAMS> static void run_read(const char *name, const void *buf, void *sink, size_t bytes) {
     const size_t n = bytes / sizeof(T) / STREAMS;
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    double ms = time_ms([&] { hipLaunchKernelGGL((k_read<T, NT, STREAMS>), dim3(blocks), dim3(256), 0, 0, (const T *)buf, (T *)sink, n); });
+    double ms = time_ms([&] { hipLaunchKernelGGL((k_read<T, NT, STREAMS>), dim3(blocks), dim3(256), g_lds, 0, (const T *)buf, (T *)sink, n); });
     printf("%-28s %8.1f GB/s  (%.3f ms, %zu bytes read)\n", name, n * STREAMS * sizeof(T) / ms / 1e6, ms, n * STREAMS * sizeof(T));
 }
 
 template <typename T, bool NT> static void run_copy(const char *name, const void *in, void *out, size_t bytes) {
     const size_t n = bytes / sizeof(T);
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    double ms = time_ms([&] { hipLaunchKernelGGL((k_copy<T, NT>), dim3(blocks), dim3(256), 0, 0, (const T *)in, (T *)out, n); });
+    double ms = time_ms([&] { hipLaunchKernelGGL((k_copy<T, NT>), dim3(blocks), dim3(256), g_lds, 0, (const T *)in, (T *)out, n); });
     printf("%-28s %8.1f GB/s  (%.3f ms, %zu bytes read + %zu written)\n", name, 2.0 * n * sizeof(T) / ms / 1e6, ms, n * sizeof(T), n * sizeof(T));
 }
 
 template <typename T, bool NT, int STREAMS> static void run_write(const char *name, void *buf, size_t bytes) {
     const size_t n = bytes / sizeof(T) / STREAMS;
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    double ms = time_ms([&] { hipLaunchKernelGGL((k_write<T, NT, STREAMS>), dim3(blocks), dim3(256), 0, 0, (T *)buf, n); });
+    double ms = time_ms([&] { hipLaunchKernelGGL((k_write<T, NT, STREAMS>), dim3(blocks), dim3(256), g_lds, 0, (T *)buf, n); });
     printf("%-28s %8.1f GB/s  (%.3f ms, %zu bytes written)\n", name, n * STREAMS * sizeof(T) / ms / 1e6, ms, n * STREAMS * sizeof(T));
 }
 
@@ -132,13 +134,15 @@ template <typename T, int RS, int WS, bool WIDE> static void run_mix(const char 
     n &= ~(size_t)255;
     const unsigned blocks = (unsigned)(n / 256);
     double ms;
-    if constexpr (WIDE) ms = time_ms([&] { hipLaunchKernelGGL((k_mix_wide<RS, WS>), dim3(blocks), dim3(256), 0, 0, (const f2v *)in, (f2v *)out, n); });
-    else ms = time_ms([&] { hipLaunchKernelGGL((k_mix<T, RS, WS>), dim3(blocks), dim3(256), 0, 0, (const T *)in, (T *)out, n); });
+    if constexpr (WIDE) ms = time_ms([&] { hipLaunchKernelGGL((k_mix_wide<RS, WS>), dim3(blocks), dim3(256), g_lds, 0, (const f2v *)in, (f2v *)out, n); });
+    else ms = time_ms([&] { hipLaunchKernelGGL((k_mix<T, RS, WS>), dim3(blocks), dim3(256), g_lds, 0, (const T *)in, (T *)out, n); });
     const double b = (double)n * sizeof(T) * (RS + WS);
     printf("%-28s %8.1f GB/s  (%.3f ms, %d read + %d write streams)\n", name, b / ms / 1e6, ms, RS, WS);
 }
 
 int main(int argc, char **argv) {
+    // second argument: resident 256-thread workgroups per CU (LDS granules of 1280 B, 128 per CU); 0 = whatever fits
+    if (argc > 2 && atoi(argv[2]) >= 3) g_lds = (128u / (unsigned)atoi(argv[2])) * 1280u;
     const size_t bytes = (argc > 1 ? (size_t)atoll(argv[1]) : 2048) << 20;  // MiB
     void *a, *b;
     CK(hipMalloc(&a, bytes));
