@@ -88,6 +88,12 @@ hipError_t compact_hits(const uint32_t *flags, const float *const tmin[4], uint6
                         uint32_t *blockcnt, unsigned long long *offsets64, unsigned long long *total, uint64_t capacity, uint32_t *out_item,
                         uint32_t *out_child, float *out_tmin, hipStream_t s);
 
+// hierarchy construction on the device (build_device.hip)
+uint32_t bvh_device_depth(uint32_t n_tris, uint32_t leaf_size);
+size_t bvh_device_workspace(uint32_t n_tris);
+hipError_t bvh_build_device(const float *tris, uint32_t n, uint32_t leaf_size, char *workspace, size_t workspace_bytes, float *out_nodes,
+                            float *out_tris, uint32_t *out_order, hipStream_t s);
+
 // traversal driver (trace.hip); queues hold (ray, node or leaf reference) pairs of 8 bytes
 hipError_t trace_validate(const float *nodes, uint32_t n_nodes, uint32_t n_tris, uint32_t *bad, hipStream_t s);
 hipError_t trace_init(const float *const origin[3], const float *const dir[3], uint32_t n, float extent, float *rays,
