@@ -65,6 +65,7 @@ def parse():
     p.add_argument("--stream-mode", type=int, default=0, help="record streams: 0 automatic, 1 partition by opcode first, 2 fused single pass")
     p.add_argument("--trace-wavefront", type=int, default=0, help="1: breadth-first walk with queue compaction; 0: depth-first walk")
     p.add_argument("--trace-sorted", type=int, default=0, help="1: rays sorted by origin / target cell (coherent waves)")
+    p.add_argument("--trace-build", default="host", help="host: median-split builder on the CPU; device: rt_dp_bvh4_build_device (Morton order) on the GPU")
     p.add_argument("--trace-log2-tris", type=int, default=18)
     p.add_argument("--trace-log2-rays", type=int, default=22)
     p.add_argument("--knn-tree", type=int, default=2, help="1: walk the k-d tree index with box pruning; 2: leaf-major search on the same index; 0: exhaustive scan")
@@ -338,9 +339,19 @@ def run_trace(a, world, rank, local, dev):
     from raytracer_amd import bvh
     n_tris, n_rays = 1 << a.trace_log2_tris, 1 << a.trace_log2_rays
     tris = bvh.random_scene(n_tris)
-    t0 = time.perf_counter()
-    nodes, tris12, _ = bvh.build_bvh4(tris, leaf_size=4)
-    build_s = time.perf_counter() - t0
+    ctx = capi.Context(device=local)
+    if a.trace_build == "device":
+        T9 = torch.from_numpy(tris).to(dev)
+        ctx.bvh4_build_device(T9, 4)          # first call: workspace allocation
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        N, T, _ = ctx.bvh4_build_device(T9, 4)
+        build_s = time.perf_counter() - t0
+    else:
+        t0 = time.perf_counter()
+        nodes, tris12, _ = bvh.build_bvh4(tris, leaf_size=4)
+        build_s = time.perf_counter() - t0
+        N, T = torch.from_numpy(nodes).to(dev), torch.from_numpy(tris12).to(dev)
     org, dirs = bvh.rays_towards(tris, n_rays, seed=20241015 + rank)
     if a.trace_sorted:  # neighbouring lanes get neighbouring rays: sort by the cell of the origin, then of the target
         cell = lambda p: np.clip(((p + 1000.0) / 2000.0 * 16).astype(np.int64), 0, 15)
@@ -348,12 +359,10 @@ def run_trace(a, world, rank, local, dev):
         key = ((co[:, 0] * 16 + co[:, 1]) * 16 + co[:, 2]) * 4096 + (ct[:, 0] * 16 + ct[:, 1]) * 16 + ct[:, 2]
         order = np.argsort(key, kind="stable")
         org, dirs = org[order], dirs[order]
-    N, T = torch.from_numpy(nodes).to(dev), torch.from_numpy(tris12).to(dev)
     o = [torch.from_numpy(np.ascontiguousarray(org[:, c])).to(dev) for c in range(3)]
     d = [torch.from_numpy(np.ascontiguousarray(dirs[:, c])).to(dev) for c in range(3)]
     out_t = torch.empty(n_rays, dtype=torch.float32, device=dev)
     out_i = torch.empty(n_rays, dtype=torch.int32, device=dev)
-    ctx = capi.Context(device=local)
     torch.cuda.synchronize()
     for _ in range(a.warmup):
         stats = ctx.trace_closest(N, T, o, d, 4000.0, out_t, out_i, wavefront=bool(a.trace_wavefront))
@@ -370,8 +379,8 @@ def run_trace(a, world, rank, local, dev):
         print(json.dumps({"metric": "rays/s (closest hit, BVH4 %s traversal on the datapath ops)" % ("wavefront" if a.trace_wavefront else "depth-first"), "value": round(n_rays * world / per, 1),
                           "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(per * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "trace: 2^%d triangles, 2^%d %s rays per GPU, leaf size 4, hierarchy built on the host in %.1f s (not timed)" % (
-                              a.trace_log2_tris, a.trace_log2_rays, "cell-sorted" if a.trace_sorted else "unsorted", build_s)},
+                          "config": {"workload": "trace: 2^%d triangles, 2^%d %s rays per GPU, leaf size 4, hierarchy built on the %s in %.4f s (not timed)" % (
+                              a.trace_log2_tris, a.trace_log2_rays, "cell-sorted" if a.trace_sorted else "unsorted", a.trace_build, build_s)},
                           "per_call": {k: int(v) for k, v in stats.items()}, "hit_fraction": round(hits, 4),
                           "box_ops_per_s": round(stats["box_ops"] / per, 1), "tri_ops_per_s": round(stats["tri_ops"] / per, 1)}), flush=True)
     ctx.close()

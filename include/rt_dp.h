@@ -443,17 +443,15 @@ int rt_dp_bvh4_build_host(const float *tris, uint32_t n_tris, uint32_t leaf_size
                           uint32_t *out_order);
 
 /* ---- the same hierarchy built on the GPU -------------------------------------------------
- * No counterpart in the reference.  A linear construction: the triangles are ordered along a Morton
- * curve through their centroids (radix sort) and every node quarters its range of that order by
- * count, down to leaves of at most leaf_size (1..8) triangles; boxes are exact.  The tree is complete:
- * rt_dp_bvh4_device_nodes(n_tris, leaf_size) rows of out_nodes[][32] are written, always that many.
- * tris [n_tris][9], out_tris [n_tris][12] (leaf order), out_order[i] = the caller's index of stored
- * triangle i: device pointers, out_nodes / out_tris 16-byte aligned.  Coarser than the host builder's
- * median splits (more nodes visited per ray), but built in about a millisecond per million
- * triangles.  Synchronous; scratch grows inside the context.                                  */
-uint32_t rt_dp_bvh4_device_nodes(uint32_t n_tris, uint32_t leaf_size);
-int rt_dp_bvh4_build_device(rt_dp_ctx *ctx, const float *tris, uint32_t n_tris, uint32_t leaf_size, float *out_nodes, float *out_tris,
-                            uint32_t *out_order);
+ * No counterpart in the reference.  A linear (LBVH-style) construction: the triangles are ordered
+ * along a Morton curve through their centroids (radix sort), a node's range of that order is halved
+ * twice where the highest differing bit of the codes flips, parts of at most leaf_size (1..8)
+ * triangles become leaves; boxes are exact.  out_nodes must hold rt_dp_bvh4_max_nodes(n_tris) rows of
+ * 32 words; *out_n_nodes (host) receives the rows in use.  tris [n_tris][9], out_tris [n_tris][12]
+ * (leaf order), out_order[i] = the caller's index of stored triangle i: device pointers, out_nodes /
+ * out_tris 16-byte aligned.  Synchronous; scratch grows inside the context.                    */
+int rt_dp_bvh4_build_device(rt_dp_ctx *ctx, const float *tris, uint32_t n_tris, uint32_t leaf_size, float *out_nodes, uint32_t *out_n_nodes,
+                            float *out_tris, uint32_t *out_order);
 
 /* ---- tuning and diagnostics ---------------------------------------------------
  * Kernel-shape knobs (0 = library default), for A/B measurements; results do not

@@ -124,7 +124,7 @@ class KnnTree(C.Structure):
                 ("points", C.c_void_p), ("index", C.c_void_p), ("leaf_lo", C.c_void_p), ("leaf_hi", C.c_void_p)]
 
 EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize",
-           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_knn_angular16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_box_compact", "rt_dp_bvh4_device_nodes", "rt_dp_bvh4_build_device", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
+           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_knn_angular16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_box_compact", "rt_dp_bvh4_build_device", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
            "rt_dp_knn_tree_leaves", "rt_dp_knn_tree_build_host", "rt_dp_knn_home_leaf_host", "rt_dp_bvh4_max_nodes", "rt_dp_bvh4_build_host",
            "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
 
@@ -167,9 +167,7 @@ def load():
     L.rt_dp_knn_angular16.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.rt_dp_knn_tree_euclid16.argtypes = [vp, C.POINTER(KnnTree), vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     L.rt_dp_knn_tree_grouped_euclid16.argtypes = [vp, C.POINTER(KnnTree), vp, vp, C.c_uint32, C.c_uint32, vp, vp, C.POINTER(C.c_uint64 * 4)]
-    L.rt_dp_bvh4_device_nodes.argtypes = [C.c_uint32, C.c_uint32]
-    L.rt_dp_bvh4_device_nodes.restype = C.c_uint32
-    L.rt_dp_bvh4_build_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp]
+    L.rt_dp_bvh4_build_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.POINTER(C.c_uint32), vp, vp]
     L.rt_dp_box_compact.argtypes = [vp, C.POINTER(BoxOut), C.c_uint64, vp, vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.rt_dp_trace_closest.argtypes = [vp, C.POINTER(Bvh4), C.POINTER(vp * 3), C.POINTER(vp * 3), C.c_uint32, C.c_float, C.c_uint32, vp, vp,
                                       C.POINTER(C.c_uint64 * 4)]
@@ -444,13 +442,15 @@ class Context:
         import torch
         assert tris.is_cuda and tris.is_contiguous() and tris.dtype == torch.float32 and tris.shape[1] == 9
         n = int(tris.shape[0])
-        m = int(self._L.rt_dp_bvh4_device_nodes(n, leaf_size))
-        if m == 0:
+        if not (1 <= n <= 1 << 28 and 1 <= leaf_size <= 8):
             raise ValueError("n must be 1 .. 2^28 and leaf_size 1 .. 8")
-        nodes = torch.empty((m, 32), dtype=torch.float32, device=tris.device)
+        cap = int(self._L.rt_dp_bvh4_max_nodes(n))
+        nodes = torch.empty((cap, 32), dtype=torch.float32, device=tris.device)
         tris12 = torch.empty((n, 12), dtype=torch.float32, device=tris.device)
         order = torch.empty(n, dtype=torch.int32, device=tris.device)
-        _check(self._L.rt_dp_bvh4_build_device(self._h, tris.data_ptr(), n, leaf_size, nodes.data_ptr(), tris12.data_ptr(), order.data_ptr()))
+        m = C.c_uint32(0)
+        _check(self._L.rt_dp_bvh4_build_device(self._h, tris.data_ptr(), n, leaf_size, nodes.data_ptr(), C.byref(m), tris12.data_ptr(), order.data_ptr()))
+        nodes = nodes[:m.value]
         return nodes, tris12, order
 
     def trace_closest(self, nodes, tris, origin, direction, extent, out_t, out_tri, wavefront=False):

@@ -966,14 +966,10 @@ int rt_dp_trace_closest(rt_dp_ctx *ctx, const rt_dp_bvh4 *bvh, const float *cons
     return RT_DP_OK;
 }
 
-uint32_t rt_dp_bvh4_device_nodes(uint32_t n_tris, uint32_t leaf_size) {
-    if (n_tris == 0 || leaf_size == 0 || leaf_size > 8 || n_tris > (1u << 28)) return 0;
-    return (uint32_t)(((1ull << (2 * bvh_device_depth(n_tris, leaf_size))) - 1) / 3);
-}
-
-int rt_dp_bvh4_build_device(rt_dp_ctx *ctx, const float *tris, uint32_t n_tris, uint32_t leaf_size, float *out_nodes, float *out_tris,
-                            uint32_t *out_order) {
-    if (!ctx || !tris || !out_nodes || !out_tris || !out_order) return fail(RT_DP_ENULL, "rt_dp_bvh4_build_device: NULL argument");
+int rt_dp_bvh4_build_device(rt_dp_ctx *ctx, const float *tris, uint32_t n_tris, uint32_t leaf_size, float *out_nodes, uint32_t *out_n_nodes,
+                            float *out_tris, uint32_t *out_order) {
+    if (!ctx || !tris || !out_nodes || !out_n_nodes || !out_tris || !out_order) return fail(RT_DP_ENULL, "rt_dp_bvh4_build_device: NULL argument");
+    *out_n_nodes = 0;
     if (n_tris == 0 || n_tris > (1u << 28)) return fail(RT_DP_EINVAL, "n_tris must be 1 .. 2^28");
     if (leaf_size == 0 || leaf_size > 8) return fail(RT_DP_EINVAL, "leaf_size must be 1 .. 8");
     if ((reinterpret_cast<uintptr_t>(tris) | reinterpret_cast<uintptr_t>(out_order)) & 3u) return fail(RT_DP_EALIGN, "tris / out_order must be 4-byte aligned");
@@ -985,7 +981,8 @@ int rt_dp_bvh4_build_device(rt_dp_ctx *ctx, const float *tris, uint32_t n_tris, 
     const size_t need = bvh_device_workspace(n_tris);
     int rc = regrow(ctx->d_trace, ctx->trace_bytes, need, "hierarchy construction");
     if (rc != RT_DP_OK) return rc;
-    HIP_TRY(bvh_build_device(tris, n_tris, leaf_size, ctx->d_trace, ctx->trace_bytes, out_nodes, out_tris, out_order, ctx->stream));
+    HIP_TRY(bvh_build_device(tris, n_tris, leaf_size, ctx->d_trace, ctx->trace_bytes, out_nodes, rt_dp_bvh4_max_nodes(n_tris), out_n_nodes, out_tris,
+                             out_order, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RT_DP_OK;
 }

@@ -89,10 +89,9 @@ hipError_t compact_hits(const uint32_t *flags, const float *const tmin[4], uint6
                         uint32_t *out_child, float *out_tmin, hipStream_t s);
 
 // hierarchy construction on the device (build_device.hip)
-uint32_t bvh_device_depth(uint32_t n_tris, uint32_t leaf_size);
 size_t bvh_device_workspace(uint32_t n_tris);
 hipError_t bvh_build_device(const float *tris, uint32_t n, uint32_t leaf_size, char *workspace, size_t workspace_bytes, float *out_nodes,
-                            float *out_tris, uint32_t *out_order, hipStream_t s);
+                            uint32_t node_capacity, uint32_t *n_nodes, float *out_tris, uint32_t *out_order, hipStream_t s);
 
 // traversal driver (trace.hip); queues hold (ray, node or leaf reference) pairs of 8 bytes
 hipError_t trace_validate(const float *nodes, uint32_t n_nodes, uint32_t n_tris, uint32_t *bad, hipStream_t s);

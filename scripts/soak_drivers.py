@@ -114,6 +114,14 @@ def soak_trace(rng, seed):
         torch.cuda.synchronize()
         stats = c.trace_closest(N, T, o, d, extent, t, i, wavefront=wavefront)
         ok &= same(t.cpu().numpy(), wt) and np.array_equal(i.cpu().numpy().view(u32), wi) and stats == wstats
+    # the same rays through a hierarchy built on the device: the walk equals the CPU model on those arrays
+    DN, DT, _ = c.bvh4_build_device(torch.from_numpy(tris).cuda(), leaf)
+    wt, wi, wstats = trace_closest_dfs(O, DN.cpu().numpy(), DT.cpu().numpy(), org, dirs, extent)
+    t = torch.empty(n_rays, dtype=torch.float32, device="cuda")
+    i = torch.empty(n_rays, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    stats = c.trace_closest(DN, DT, o, d, extent, t, i, wavefront=False)
+    ok &= same(t.cpu().numpy(), wt) and np.array_equal(i.cpu().numpy().view(u32), wi) and stats == wstats
     c.close()
     return ok, "trace tris=%d rays=%d leaf=%d" % (n_tris, n_rays, leaf)
 

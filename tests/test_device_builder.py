@@ -50,7 +50,7 @@ def test_device_built_hierarchy_is_a_partition_with_exact_boxes(ctx, torch_cuda,
         tris[7] = tris[8]                      # coincident triangles: equal Morton codes
         tris[9, 4] = np.inf                    # a vertex at infinity: a centroid outside every cell
     nodes, tris12, order = ctx.bvh4_build_device(torch.from_numpy(tris).cuda(), leaf)
-    assert nodes.shape[0] == capi.load().rt_dp_bvh4_device_nodes(n, leaf)
+    assert 1 <= nodes.shape[0] <= n
     check_structure(nodes.cpu().numpy(), tris12.cpu().numpy(), order.cpu().numpy().view(u32).astype(np.int64), tris, leaf)
 
 
@@ -95,6 +95,8 @@ def test_device_builder_argument_errors(ctx, torch_cuda):
     n = torch.zeros((8, 32), dtype=torch.float32, device="cuda")
     o = torch.zeros((4, 12), dtype=torch.float32, device="cuda")
     p = torch.zeros(4, dtype=torch.int32, device="cuda")
-    assert L.rt_dp_bvh4_build_device(ctx._h, t.data_ptr(), 4, 9, n.data_ptr(), o.data_ptr(), p.data_ptr()) == capi.EINVAL
-    assert L.rt_dp_bvh4_build_device(ctx._h, t.data_ptr(), 0, 4, n.data_ptr(), o.data_ptr(), p.data_ptr()) == capi.EINVAL
-    assert L.rt_dp_bvh4_build_device(ctx._h, t.data_ptr(), 4, 4, n.data_ptr() + 4, o.data_ptr(), p.data_ptr()) == capi.EALIGN
+    import ctypes as C
+    m = C.c_uint32(0)
+    assert L.rt_dp_bvh4_build_device(ctx._h, t.data_ptr(), 4, 9, n.data_ptr(), C.byref(m), o.data_ptr(), p.data_ptr()) == capi.EINVAL
+    assert L.rt_dp_bvh4_build_device(ctx._h, t.data_ptr(), 0, 4, n.data_ptr(), C.byref(m), o.data_ptr(), p.data_ptr()) == capi.EINVAL
+    assert L.rt_dp_bvh4_build_device(ctx._h, t.data_ptr(), 4, 4, n.data_ptr() + 4, C.byref(m), o.data_ptr(), p.data_ptr()) == capi.EALIGN
