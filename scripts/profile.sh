@@ -28,7 +28,7 @@ for wl in box tri euclid angular; do
 done
 # the drivers above the op kernels: record stream (both modes), k-NN (exhaustive and tree), traversal (both walks)
 for spec in "stream1:--only stream --stream-mode 1" "stream2:--only stream --stream-mode 2" "knn_exhaustive:--only knn --knn-tree 0" \
-            "knn_tree_walk:--only knn --knn-tree 1" "knn_tree_leafmajor:--only knn --knn-tree 2" "trace_dfs:--only trace" "trace_dfs_sorted:--only trace --trace-sorted 1" "trace_wavefront:--only trace --trace-wavefront 1" \
+            "knn_tree_walk:--only knn --knn-tree 1" "knn_tree_leafmajor:--only knn --knn-tree 2" "trace_dfs:--only trace" "trace_dfs_sorted:--only trace --trace-sorted 1" "trace_wavefront:--only trace --trace-wavefront 1" "trace_device_built:--only trace --trace-build device" \
             "knn_angular:--only knn --knn-tree 0 --knn-metric angular" "derive_box:--only box --derive 1 --no-cpu-baseline" "derive_tri:--only tri --derive 1 --no-cpu-baseline"; do
     name=${spec%%:*}; args=${spec#*:}
     run "kt_$name" 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$name" -- python3 $ROOT/bench.py --steps 3 --warmup 1 $args

@@ -66,9 +66,11 @@ if drivers:
             for path in glob.glob(os.path.join(d, "*", "*kernel_trace.csv")):
                 with open(path, newline="") as fh:
                     for r in csv.DictReader(fh):
-                        m = re.search(r"rtdp::(k_\w+)(<[^>]*>)?", r["Kernel_Name"])
+                        m = re.search(r"rtdp::(?:\(anonymous namespace\)::)?(k_\w+)(<[^>]*>)?", r["Kernel_Name"])
                         if m:
                             per[m.group(1) + (m.group(2) or "")].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                        elif "rocprim" in r["Kernel_Name"]:   # the builder's radix sort and scans (hipcub)
+                            per["rocprim sort / scan kernels"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
             f.write("\n## %s\n\n| kernel | calls | avg us | total ms |\n|---|---|---|---|\n" % os.path.basename(d)[3:])
             for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
                 f.write("| `%s` | %d | %.1f | %.2f |\n" % (k, len(v), sum(v) / len(v) / 1e3, sum(v) / 1e6))
