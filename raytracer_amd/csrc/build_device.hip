@@ -59,8 +59,9 @@ __global__ __launch_bounds__(256) void k_bvh_bounds(const float *__restrict__ tr
     if ((threadIdx.x & 63u) == 0u) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            if (lo[a] != 0xFFFFFFFFu) atomicMin(&bounds[a], lo[a]);
-            if (hi[a] != 0u) atomicMax(&bounds[3 + a], hi[a]);
+            // thousands of waves would queue up on six words: go to the atomic only when the value read improves the bound
+            if (lo[a] < __hip_atomic_load(&bounds[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&bounds[a], lo[a]);
+            if (hi[a] > __hip_atomic_load(&bounds[3 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&bounds[3 + a], hi[a]);
         }
     }
 }
