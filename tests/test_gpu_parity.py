@@ -43,6 +43,25 @@ def test_box_kernel_shapes(ctx, oracle, torch_cuda, v, nt):
     check_box(ctx, oracle, gen.box_ops(200003, seed=7, edge_frac=0.25), True, torch_cuda)
 
 
+@pytest.mark.parametrize("wgs", [3, 4, 7, 16, 99])
+def test_residency_caps_do_not_change_results(ctx, oracle, torch_cuda, wgs):
+    """The dynamic-LDS residency cap of the op kernels is a scheduling knob: every legal value launches and gives the
+    oracle's bits, for all four opcodes (batches above the sizes from which the default cap applies)."""
+    ctx.set_option("wgs_per_cu", wgs)
+    check_box(ctx, oracle, gen.box_ops((1 << 20) + 3, seed=70 + wgs, edge_frac=0.1), True, torch_cuda)
+    tf, tk = gen.tri_ops((1 << 21) + 5, seed=80 + wgs, edge_frac=0.1)
+    check_tri(ctx, oracle, tf, tk, True, torch_cuda)
+    a, b, ctl, _ = gen.vec_beats(30000, 16, seed=90 + wgs, edge_frac=0.05)
+    assert_bits_equal(hip_euclid(ctx, a, b, ctl, True, torch_cuda), oracle.euclid_beats(a, b, ctl)[0], "euclid")
+    q, c, ctl8, _ = gen.vec_beats(30000, 8, seed=95 + wgs, edge_frac=0.05)
+    gd, gn = hip_angular(ctx, q, c, ctl8, True, torch_cuda)
+    wd, wn = oracle.angular_beats(q, c, ctl8)[:2]
+    assert_bits_equal(gd, wd, "angular dot")
+    assert_bits_equal(gn, wn, "angular norm")
+    with pytest.raises(capi.RtDpError):
+        ctx.set_option("wgs_per_cu", 2)
+
+
 def test_box_random_1m(ctx, oracle, torch_cuda):
     check_box(ctx, oracle, gen.box_ops(1 << 20, seed=20241008, edge_frac=0.0), True, torch_cuda)
 
