@@ -143,3 +143,35 @@ def test_trace_argument_errors(ctx, torch_cuda):
     assert call(empty, 0) == capi.EINVAL                               # no root
     wrong = capi.Bvh4(8, nodes.shape[0], tris12.shape[0], 0, N.data_ptr(), T.data_ptr())
     assert call(wrong, 0) == capi.EINVAL                               # struct_size
+
+
+@pytest.mark.gpu
+def test_depth_first_walk_is_independent_of_which_lane_takes_a_ray(ctx, torch_cuda):
+    """More rays than the persistent grid has lanes (2048 workgroups of 256): lanes fetch further rays from the global
+    counter as they finish.  Every ray must get what it gets when traced in batches small enough to need no refill."""
+    torch = torch_cuda
+    tris = bvh.random_scene(3000, seed=5)
+    nodes, tris12, _ = bvh.build_bvh4(tris, leaf_size=4)
+    n = 2048 * 256 + 70001
+    org, dirs = bvh.rays_towards(tris, n, seed=6, jitter=4.0)
+    N, T = torch.from_numpy(nodes).cuda(), torch.from_numpy(tris12).cuda()
+    O, D = torch.from_numpy(org).cuda(), torch.from_numpy(dirs).cuda()
+
+    def trace(a, b):
+        o = [O[a:b, c].contiguous() for c in range(3)]
+        d = [D[a:b, c].contiguous() for c in range(3)]
+        t = torch.empty(b - a, dtype=torch.float32, device="cuda")
+        i = torch.empty(b - a, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        stats = ctx.trace_closest(N, T, o, d, 4000.0, t, i)
+        return t, i, stats
+
+    t_all, i_all, s_all = trace(0, n)
+    box = tri = 0
+    for a in range(0, n, 100000):
+        b = min(n, a + 100000)
+        t, i, s = trace(a, b)
+        assert torch.equal(t.view(torch.int32), t_all[a:b].view(torch.int32)) and torch.equal(i, i_all[a:b])
+        box += s["box_ops"]
+        tri += s["tri_ops"]
+    assert (box, tri) == (s_all["box_ops"], s_all["tri_ops"])
