@@ -263,6 +263,25 @@ int rt_dp_eval_bundles(rt_dp_ctx *ctx, const rt_dp_input_bundle *in, rt_dp_outpu
  * the GPU; only the four per-opcode counts travel to the host.  Synchronous.           */
 int rt_dp_eval_bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt_dp_output_bundle *d_out, uint64_t n);
 
+/* ---- vector pairs <-> beats (the format step on either side of the distance ops) ---------
+ * The reference's job splitters (src/test/scala/raytracer_datapath/raytracer_gold/SW_Data.scala:
+ * 213-269 Euclidean, :271-308 angular): a pair of vectors of `len` elements becomes ceil(len / width)
+ * beats (width 16 for the Euclidean op, 8 for the angular op), the last one zero-padded, mask = the
+ * low min(width, remaining) bits, reset bit on the last beat; an empty pair yields no beat.
+ *   pair_offsets[n_pairs + 1]  element offset of every pair in a / b, ascending, [0] = 0
+ *   beat_offsets[n_pairs + 1]  beat offset of every pair; rt_dp_beat_offsets_host fills it from
+ *                              pair_offsets (host arrays) and returns the number of beats
+ * rt_dp_pairs_to_beats writes the segment a beat kernel reads: out_a / out_b [n_beats][width],
+ * out_ctl[n_beats]; rt_dp_beats_to_pairs picks, per pair, the value of its last beat out of a
+ * result array (what the reference's tests read: Datapath_test.scala:287-290, :353-356), +0 for an
+ * empty pair.  Device pointers (offsets 8-byte, the rest 4-byte aligned); asynchronous on
+ * `hip_stream` (NULL = context stream).                                                         */
+uint64_t rt_dp_beat_offsets_host(const uint64_t *pair_offsets, uint64_t n_pairs, uint32_t width, uint64_t *beat_offsets);
+int rt_dp_pairs_to_beats(rt_dp_ctx *ctx, const float *a, const float *b, const uint64_t *pair_offsets, const uint64_t *beat_offsets,
+                         uint64_t n_pairs, uint64_t n_beats, uint32_t width, float *out_a, float *out_b, uint32_t *out_ctl, void *hip_stream);
+int rt_dp_beats_to_pairs(rt_dp_ctx *ctx, const float *values, const uint64_t *beat_offsets, uint64_t n_pairs, float *out_pair_values,
+                         void *hip_stream);
+
 /* ---- ray pre-processing (the step in front of the datapath) ---------------------------
  * Derives, on the GPU, the ray fields that the reference's software model computes from
  * (origin, dir) before it pokes a record: inv, kx/ky/kz and shear of SW_Ray

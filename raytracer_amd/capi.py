@@ -124,7 +124,7 @@ class KnnTree(C.Structure):
                 ("points", C.c_void_p), ("index", C.c_void_p), ("leaf_lo", C.c_void_p), ("leaf_hi", C.c_void_p)]
 
 EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize",
-           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_knn_angular16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_box_compact", "rt_dp_bvh4_build_device", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
+           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_knn_angular16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_box_compact", "rt_dp_beat_offsets_host", "rt_dp_pairs_to_beats", "rt_dp_beats_to_pairs", "rt_dp_bvh4_build_device", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
            "rt_dp_knn_tree_leaves", "rt_dp_knn_tree_build_host", "rt_dp_knn_home_leaf_host", "rt_dp_bvh4_max_nodes", "rt_dp_bvh4_build_host",
            "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
 
@@ -168,6 +168,10 @@ def load():
     L.rt_dp_knn_tree_euclid16.argtypes = [vp, C.POINTER(KnnTree), vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     L.rt_dp_knn_tree_grouped_euclid16.argtypes = [vp, C.POINTER(KnnTree), vp, vp, C.c_uint32, C.c_uint32, vp, vp, C.POINTER(C.c_uint64 * 4)]
     L.rt_dp_bvh4_build_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.POINTER(C.c_uint32), vp, vp]
+    L.rt_dp_beat_offsets_host.argtypes = [vp, C.c_uint64, C.c_uint32, vp]
+    L.rt_dp_beat_offsets_host.restype = C.c_uint64
+    L.rt_dp_pairs_to_beats.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp, vp, vp]
+    L.rt_dp_beats_to_pairs.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
     L.rt_dp_box_compact.argtypes = [vp, C.POINTER(BoxOut), C.c_uint64, vp, vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.rt_dp_trace_closest.argtypes = [vp, C.POINTER(Bvh4), C.POINTER(vp * 3), C.POINTER(vp * 3), C.c_uint32, C.c_float, C.c_uint32, vp, vp,
                                       C.POINTER(C.c_uint64 * 4)]
@@ -435,6 +439,36 @@ class Context:
         _check(self._L.rt_dp_box_compact(self._h, C.byref(ro), n, p(item), p(children), p(out_item), p(out_child), p(out_tmin),
                                          int(out_item.shape[0]), C.byref(count)))
         return int(count.value)
+
+    def pairs_to_beats(self, a, b, pair_offsets, width):
+        """Vector pairs (flat float32 CUDA tensors a, b; pair_offsets: int64 numpy array [n_pairs + 1]) split into
+        beats of `width` elements.  Returns (a_beats [n, width], b_beats [n, width], ctl int32 [n], beat_offsets int64
+        CUDA tensor [n_pairs + 1])."""
+        import torch
+        po = np.ascontiguousarray(pair_offsets, np.uint64)
+        n_pairs = po.shape[0] - 1
+        bo = np.zeros(n_pairs + 1, np.uint64)
+        n_beats = int(self._L.rt_dp_beat_offsets_host(po.ctypes.data, n_pairs, width, bo.ctypes.data))
+        d_po = torch.from_numpy(po.view(np.int64)).to(a.device)
+        d_bo = torch.from_numpy(bo.view(np.int64)).to(a.device)
+        oa = torch.empty((n_beats, width), dtype=torch.float32, device=a.device)
+        ob = torch.empty((n_beats, width), dtype=torch.float32, device=a.device)
+        ctl = torch.empty(n_beats, dtype=torch.int32, device=a.device)
+        torch.cuda.synchronize()
+        _check(self._L.rt_dp_pairs_to_beats(self._h, a.data_ptr(), b.data_ptr(), d_po.data_ptr(), d_bo.data_ptr(), n_pairs, n_beats, width,
+                                            oa.data_ptr(), ob.data_ptr(), ctl.data_ptr(), None))
+        self.synchronize()
+        return oa, ob, ctl, d_bo
+
+    def beats_to_pairs(self, values, beat_offsets):
+        """Per pair, the value of its last beat (float32 CUDA tensor [n_pairs])."""
+        import torch
+        n_pairs = int(beat_offsets.shape[0]) - 1
+        out = torch.empty(n_pairs, dtype=torch.float32, device=values.device)
+        torch.cuda.synchronize()
+        _check(self._L.rt_dp_beats_to_pairs(self._h, values.data_ptr(), beat_offsets.data_ptr(), n_pairs, out.data_ptr(), None))
+        self.synchronize()
+        return out
 
     def bvh4_build_device(self, tris, leaf_size=4):
         """Hierarchy over tris (float32 CUDA tensor [n, 9]) built on the GPU.  Returns (nodes [m, 32] float32,

@@ -827,6 +827,50 @@ int rt_dp_knn_tree_grouped_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, 
     return RT_DP_OK;
 }
 
+uint64_t rt_dp_beat_offsets_host(const uint64_t *pair_offsets, uint64_t n_pairs, uint32_t width, uint64_t *beat_offsets) {
+    if (!pair_offsets || (width != 16 && width != 8)) return 0;
+    uint64_t beats = 0;
+    for (uint64_t p = 0; p < n_pairs; ++p) {
+        if (beat_offsets) beat_offsets[p] = beats;
+        const uint64_t len = pair_offsets[p + 1] >= pair_offsets[p] ? pair_offsets[p + 1] - pair_offsets[p] : 0;
+        beats += (len + width - 1) / width;
+    }
+    if (beat_offsets) beat_offsets[n_pairs] = beats;
+    return beats;
+}
+
+int rt_dp_pairs_to_beats(rt_dp_ctx *ctx, const float *a, const float *b, const uint64_t *pair_offsets, const uint64_t *beat_offsets,
+                         uint64_t n_pairs, uint64_t n_beats, uint32_t width, float *out_a, float *out_b, uint32_t *out_ctl, void *hip_stream) {
+    if (!ctx) return fail(RT_DP_ENULL, "rt_dp_pairs_to_beats: ctx is NULL");
+    if (width != 16 && width != 8) return fail(RT_DP_EINVAL, "width must be 16 (Euclidean) or 8 (angular)");
+    if (n_beats == 0) return RT_DP_OK;
+    if (n_beats > kMaxOps || n_pairs > kMaxOps) return fail(RT_DP_EINVAL, "counts are not representable (limit 2^40)");
+    if (!a || !b || !pair_offsets || !beat_offsets || !out_a || !out_b || !out_ctl || n_pairs == 0) return fail(RT_DP_ENULL, "rt_dp_pairs_to_beats: NULL array");
+    if ((reinterpret_cast<uintptr_t>(pair_offsets) | reinterpret_cast<uintptr_t>(beat_offsets)) & 7u) return fail(RT_DP_EALIGN, "offset arrays must be 8-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out_a) | reinterpret_cast<uintptr_t>(out_b) |
+         reinterpret_cast<uintptr_t>(out_ctl)) & 3u)
+        return fail(RT_DP_EALIGN, "arrays must be 4-byte aligned");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
+    HIP_TRY(pairs_to_beats(a, b, pair_offsets, beat_offsets, n_pairs, n_beats, width, out_a, out_b, out_ctl,
+                           hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
+    return RT_DP_OK;
+}
+
+int rt_dp_beats_to_pairs(rt_dp_ctx *ctx, const float *values, const uint64_t *beat_offsets, uint64_t n_pairs, float *out_pair_values,
+                         void *hip_stream) {
+    if (!ctx) return fail(RT_DP_ENULL, "rt_dp_beats_to_pairs: ctx is NULL");
+    if (n_pairs == 0) return RT_DP_OK;
+    if (n_pairs > kMaxOps) return fail(RT_DP_EINVAL, "n_pairs is not representable (limit 2^40)");
+    if (!values || !beat_offsets || !out_pair_values) return fail(RT_DP_ENULL, "rt_dp_beats_to_pairs: NULL array");
+    if (reinterpret_cast<uintptr_t>(beat_offsets) & 7u) return fail(RT_DP_EALIGN, "beat_offsets must be 8-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(values) | reinterpret_cast<uintptr_t>(out_pair_values)) & 3u) return fail(RT_DP_EALIGN, "arrays must be 4-byte aligned");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
+    HIP_TRY(beats_to_pairs(values, beat_offsets, n_pairs, out_pair_values, hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
+    return RT_DP_OK;
+}
+
 int rt_dp_box_compact(rt_dp_ctx *ctx, const rt_dp_box_out *results, uint64_t n, const uint32_t *item, const uint32_t *children,
                       uint32_t *out_item, uint32_t *out_child, float *out_tmin, uint64_t capacity, uint64_t *count) {
     if (!ctx || !results || !count) return fail(RT_DP_ENULL, "rt_dp_box_compact: NULL argument");

@@ -88,6 +88,11 @@ hipError_t compact_hits(const uint32_t *flags, const float *const tmin[4], uint6
                         uint32_t *blockcnt, unsigned long long *offsets64, unsigned long long *total, uint64_t capacity, uint32_t *out_item,
                         uint32_t *out_child, float *out_tmin, hipStream_t s);
 
+// vector pairs <-> beats (pairs.hip)
+hipError_t pairs_to_beats(const float *a, const float *b, const uint64_t *pair_offsets, const uint64_t *beat_offsets, uint64_t n_pairs,
+                          uint64_t n_beats, uint32_t width, float *out_a, float *out_b, uint32_t *out_ctl, hipStream_t s);
+hipError_t beats_to_pairs(const float *values, const uint64_t *beat_offsets, uint64_t n_pairs, float *out, hipStream_t s);
+
 // hierarchy construction on the device (build_device.hip)
 size_t bvh_device_workspace(uint32_t n_tris);
 hipError_t bvh_build_device(const float *tris, uint32_t n, uint32_t leaf_size, char *workspace, size_t workspace_bytes, float *out_nodes,
