@@ -73,6 +73,7 @@ def parse():
     p.add_argument("--knn-metric", default="euclid", help="euclid, or angular (exhaustive scan ranked by dot / sqrt(norm))")
     p.add_argument("--knn-data", default="uniform", help="uniform: U(-1,1)^16 (the named configuration); clustered: 256 Gaussian clusters, sigma 0.05")
     p.add_argument("--knn-leaf", type=int, default=128, help="points per tree leaf")
+    p.add_argument("--knn-build", default="torch", help="torch: index built by torch sort / gather per level; device: rt_dp_knn_tree_build_device")
     p.add_argument("--knn-splits", type=int, default=0, help="point splits per query block (0 = chosen by the library front-end)")
     p.add_argument("--derive", type=int, default=0, help="1: box / tri workloads derive inv / shear / k from dir inside the kernels "
                    "(RT_DP_F_DERIVE_RAY: 144 and 72 algorithmic bytes per op); not the headline format")
@@ -412,7 +413,13 @@ def run_knn(a, world, rank, local, dev):
         from raytracer_amd import knn_tree
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        tree = knn_tree.KnnTree(shard, leaf_size=a.knn_leaf, index_base=lo)  # index construction: outside the timed queries
+        if a.knn_build == "device":
+            knn_tree.KnnTree.build_device(ctx, shard, leaf_size=a.knn_leaf, index_base=lo)   # first call: workspace allocation
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tree = knn_tree.KnnTree.build_device(ctx, shard, leaf_size=a.knn_leaf, index_base=lo)
+        else:
+            tree = knn_tree.KnnTree(shard, leaf_size=a.knn_leaf, index_base=lo)  # index construction: outside the timed queries
         torch.cuda.synchronize()
         build_ms = (time.perf_counter() - t0) * 1e3
     with torch.cuda.stream(stream):

@@ -461,6 +461,22 @@ uint32_t rt_dp_bvh4_max_nodes(uint32_t n_tris);
 int rt_dp_bvh4_build_host(const float *tris, uint32_t n_tris, uint32_t leaf_size, float *out_nodes, uint32_t *out_n_nodes, float *out_tris,
                           uint32_t *out_order);
 
+/* ---- the k-d index built on the GPU -------------------------------------------------------
+ * No counterpart in the reference.  rt_dp_knn_tree_build_device is rt_dp_knn_tree_build_host on device
+ * arrays: same leaf count (rt_dp_knn_tree_leaves), same layout of out_points / out_index / out_lo /
+ * out_hi / out_split_dim / out_split_val (heap order; both split arrays or neither), the same
+ * partition rule (every segment sorted along its widest finite dimension; all segments of a level in
+ * one radix sort); ties keep their current order instead of the host builder's order by index, so the
+ * two may store equal-coordinate points in different slots.  rt_dp_knn_home_leaf is
+ * rt_dp_knn_home_leaf_host on device arrays.  points [n_points][16], queries [n_queries][16]; every
+ * pointer a device pointer, 16-byte aligned rows.  The build is synchronous (scratch grows inside
+ * the context); the home-leaf kernel is asynchronous on `hip_stream` (NULL = context stream).      */
+int rt_dp_knn_tree_build_device(rt_dp_ctx *ctx, const float *points, uint32_t n_points, uint32_t leaf_size, uint32_t index_base,
+                                float *out_points, uint32_t *out_index, float *out_lo, float *out_hi, uint32_t *out_split_dim,
+                                float *out_split_val);
+int rt_dp_knn_home_leaf(rt_dp_ctx *ctx, const float *queries, uint32_t n_queries, uint32_t n_leaves, const uint32_t *split_dim,
+                        const float *split_val, uint32_t *out_home, void *hip_stream);
+
 /* ---- the same hierarchy built on the GPU -------------------------------------------------
  * No counterpart in the reference.  A linear (LBVH-style) construction: the triangles are ordered
  * along a Morton curve through their centroids (radix sort), a node's range of that order is halved

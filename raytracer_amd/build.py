@@ -20,7 +20,7 @@ ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
           "-fno-gpu-flush-denormals-to-zero", "-Wall", "-Wno-unused-function",
           "-I", os.path.join(ROOT, "include"), "-I", CSRC]
-SOURCES = ["kernels.hip", "knn.hip", "stream.hip", "stream_fused.hip", "trace.hip", "compact.hip", "pairs.hip", "build_device.hip", "api.cpp", "build_index.cpp"]
+SOURCES = ["kernels.hip", "knn.hip", "stream.hip", "stream_fused.hip", "trace.hip", "compact.hip", "pairs.hip", "build_device.hip", "build_kd.hip", "api.cpp", "build_index.cpp"]
 HOST_TOOLS = {"rt_dp_replay": ["rt_dp_replay.cpp"]}
 
 

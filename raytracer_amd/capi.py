@@ -124,7 +124,7 @@ class KnnTree(C.Structure):
                 ("points", C.c_void_p), ("index", C.c_void_p), ("leaf_lo", C.c_void_p), ("leaf_hi", C.c_void_p)]
 
 EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize",
-           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_knn_angular16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_box_compact", "rt_dp_beat_offsets_host", "rt_dp_pairs_to_beats", "rt_dp_beats_to_pairs", "rt_dp_bvh4_build_device", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
+           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_knn_angular16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_box_compact", "rt_dp_beat_offsets_host", "rt_dp_pairs_to_beats", "rt_dp_beats_to_pairs", "rt_dp_bvh4_build_device", "rt_dp_knn_tree_build_device", "rt_dp_knn_home_leaf", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
            "rt_dp_knn_tree_leaves", "rt_dp_knn_tree_build_host", "rt_dp_knn_home_leaf_host", "rt_dp_bvh4_max_nodes", "rt_dp_bvh4_build_host",
            "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
 
@@ -172,6 +172,8 @@ def load():
     L.rt_dp_beat_offsets_host.restype = C.c_uint64
     L.rt_dp_pairs_to_beats.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp, vp, vp]
     L.rt_dp_beats_to_pairs.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
+    L.rt_dp_knn_tree_build_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp]
+    L.rt_dp_knn_home_leaf.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     L.rt_dp_box_compact.argtypes = [vp, C.POINTER(BoxOut), C.c_uint64, vp, vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.rt_dp_trace_closest.argtypes = [vp, C.POINTER(Bvh4), C.POINTER(vp * 3), C.POINTER(vp * 3), C.c_uint32, C.c_float, C.c_uint32, vp, vp,
                                       C.POINTER(C.c_uint64 * 4)]
@@ -467,6 +469,37 @@ class Context:
         out = torch.empty(n_pairs, dtype=torch.float32, device=values.device)
         torch.cuda.synchronize()
         _check(self._L.rt_dp_beats_to_pairs(self._h, values.data_ptr(), beat_offsets.data_ptr(), n_pairs, out.data_ptr(), None))
+        self.synchronize()
+        return out
+
+    def knn_tree_build_device(self, points, leaf_size=128, index_base=0):
+        """k-d index over points (float32 CUDA tensor [n, 16]) built on the GPU.  Returns a dict of CUDA tensors:
+        points [L * leaf_size, 16], index int32, leaf_lo / leaf_hi [L, 16], split_dim int32 / split_val [L - 1] (heap
+        order), and n_leaves."""
+        import torch
+        assert points.is_cuda and points.is_contiguous() and points.dtype == torch.float32 and points.shape[1] == 16
+        n = int(points.shape[0])
+        leaves = int(self._L.rt_dp_knn_tree_leaves(n, leaf_size))
+        dev = points.device
+        t = {"n_leaves": leaves, "leaf_size": leaf_size,
+             "points": torch.empty((leaves * leaf_size, 16), dtype=torch.float32, device=dev),
+             "index": torch.empty(leaves * leaf_size, dtype=torch.int32, device=dev),
+             "leaf_lo": torch.empty((leaves, 16), dtype=torch.float32, device=dev),
+             "leaf_hi": torch.empty((leaves, 16), dtype=torch.float32, device=dev),
+             "split_dim": torch.zeros(max(1, leaves - 1), dtype=torch.int32, device=dev),
+             "split_val": torch.zeros(max(1, leaves - 1), dtype=torch.float32, device=dev)}
+        _check(self._L.rt_dp_knn_tree_build_device(self._h, points.data_ptr(), n, leaf_size, index_base, t["points"].data_ptr(), t["index"].data_ptr(),
+                                                   t["leaf_lo"].data_ptr(), t["leaf_hi"].data_ptr(), t["split_dim"].data_ptr(), t["split_val"].data_ptr()))
+        return t
+
+    def knn_home_leaf(self, queries, tree):
+        """The leaf every query (float32 CUDA tensor [m, 16]) reaches in a tree from knn_tree_build_device (int32 [m])."""
+        import torch
+        m = int(queries.shape[0])
+        out = torch.empty(m, dtype=torch.int32, device=queries.device)
+        torch.cuda.synchronize()
+        _check(self._L.rt_dp_knn_home_leaf(self._h, queries.data_ptr(), m, tree["n_leaves"], tree["split_dim"].data_ptr(), tree["split_val"].data_ptr(),
+                                           out.data_ptr(), None))
         self.synchronize()
         return out
 

@@ -1010,6 +1010,47 @@ int rt_dp_trace_closest(rt_dp_ctx *ctx, const rt_dp_bvh4 *bvh, const float *cons
     return RT_DP_OK;
 }
 
+int rt_dp_knn_tree_build_device(rt_dp_ctx *ctx, const float *points, uint32_t n_points, uint32_t leaf_size, uint32_t index_base,
+                                float *out_points, uint32_t *out_index, float *out_lo, float *out_hi, uint32_t *out_split_dim,
+                                float *out_split_val) {
+    if (!ctx || !out_points || !out_index || !out_lo || !out_hi || (!points && n_points)) return fail(RT_DP_ENULL, "rt_dp_knn_tree_build_device: NULL argument");
+    if ((out_split_dim == nullptr) != (out_split_val == nullptr)) return fail(RT_DP_ENULL, "out_split_dim and out_split_val go together");
+    if (leaf_size == 0 || (leaf_size & 3u)) return fail(RT_DP_EINVAL, "leaf_size = %u is not a positive multiple of 4", leaf_size);
+    if ((uint64_t)index_base + n_points > 0xFFFFFFFFull) return fail(RT_DP_EINVAL, "index_base + n_points exceeds the 32-bit index range");
+    const uint32_t leaves = rt_dp_knn_tree_leaves(n_points, leaf_size);
+    if ((uint64_t)leaves * leaf_size > 0x7FFFFFFFull) return fail(RT_DP_EINVAL, "n_leaves * leaf_size exceeds 2^31 - 1 slots");
+    if ((reinterpret_cast<uintptr_t>(points) | reinterpret_cast<uintptr_t>(out_points) | reinterpret_cast<uintptr_t>(out_lo) |
+         reinterpret_cast<uintptr_t>(out_hi)) & 15u)
+        return fail(RT_DP_EALIGN, "rt_dp_knn_tree_build_device: coordinate arrays must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(out_index) | reinterpret_cast<uintptr_t>(out_split_dim) | reinterpret_cast<uintptr_t>(out_split_val)) & 3u)
+        return fail(RT_DP_EALIGN, "rt_dp_knn_tree_build_device: arrays must be 4-byte aligned");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
+    HIP_TRY(hipDeviceSynchronize());  // the points may still be in production on a caller stream
+    const size_t need = kd_device_workspace(leaves * leaf_size, leaves);
+    int rc = regrow(ctx->d_trace, ctx->trace_bytes, need, "index construction");
+    if (rc != RT_DP_OK) return rc;
+    HIP_TRY(kd_build_device(points, n_points, leaves, leaf_size, index_base, ctx->d_trace, ctx->trace_bytes, out_points, out_index, out_lo, out_hi,
+                            out_split_dim, out_split_val, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_DP_OK;
+}
+
+int rt_dp_knn_home_leaf(rt_dp_ctx *ctx, const float *queries, uint32_t n_queries, uint32_t n_leaves, const uint32_t *split_dim,
+                        const float *split_val, uint32_t *out_home, void *hip_stream) {
+    if (!ctx) return fail(RT_DP_ENULL, "rt_dp_knn_home_leaf: ctx is NULL");
+    if (n_queries == 0) return RT_DP_OK;
+    if (!queries || !out_home || (n_leaves > 1 && (!split_dim || !split_val))) return fail(RT_DP_ENULL, "rt_dp_knn_home_leaf: NULL array");
+    if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) return fail(RT_DP_EINVAL, "n_leaves = %u is not a power of two", n_leaves);
+    if ((reinterpret_cast<uintptr_t>(queries) | reinterpret_cast<uintptr_t>(split_dim) | reinterpret_cast<uintptr_t>(split_val) |
+         reinterpret_cast<uintptr_t>(out_home)) & 3u)
+        return fail(RT_DP_EALIGN, "rt_dp_knn_home_leaf: arrays must be 4-byte aligned");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
+    HIP_TRY(kd_home_leaf(queries, n_queries, n_leaves, split_dim, split_val, out_home, hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
+    return RT_DP_OK;
+}
+
 int rt_dp_bvh4_build_device(rt_dp_ctx *ctx, const float *tris, uint32_t n_tris, uint32_t leaf_size, float *out_nodes, uint32_t *out_n_nodes,
                             float *out_tris, uint32_t *out_order) {
     if (!ctx || !tris || !out_nodes || !out_n_nodes || !out_tris || !out_order) return fail(RT_DP_ENULL, "rt_dp_bvh4_build_device: NULL argument");

@@ -98,6 +98,14 @@ size_t bvh_device_workspace(uint32_t n_tris);
 hipError_t bvh_build_device(const float *tris, uint32_t n, uint32_t leaf_size, char *workspace, size_t workspace_bytes, float *out_nodes,
                             uint32_t node_capacity, uint32_t *n_nodes, float *out_tris, uint32_t *out_order, hipStream_t s);
 
+// k-d index construction on the device (build_kd.hip)
+size_t kd_device_workspace(uint32_t total_slots, uint32_t n_leaves);
+hipError_t kd_build_device(const float *pts, uint32_t n, uint32_t n_leaves, uint32_t leaf_size, uint32_t index_base, char *workspace,
+                           size_t workspace_bytes, float *out_points, uint32_t *out_index, float *out_lo, float *out_hi, uint32_t *split_dim,
+                           float *split_val, hipStream_t s);
+hipError_t kd_home_leaf(const float *qry, uint32_t n_qry, uint32_t n_leaves, const uint32_t *split_dim, const float *split_val, uint32_t *home,
+                        hipStream_t s);
+
 // traversal driver (trace.hip); queues hold (ray, node or leaf reference) pairs of 8 bytes
 hipError_t trace_validate(const float *nodes, uint32_t n_nodes, uint32_t n_tris, uint32_t *bad, hipStream_t s);
 hipError_t trace_init(const float *const origin[3], const float *const dir[3], uint32_t n, float extent, float *rays,

@@ -59,6 +59,19 @@ class KnnTree:
         self.index = torch.where(idx >= 2 ** 31, idx - 2 ** 32, idx).to(torch.int32).contiguous()  # bit image of the uint32 index
         self.n_leaves, self.leaf_size, self.depth, self.n_points = leaves, leaf_size, depth, n
 
+    @classmethod
+    def build_device(cls, ctx, points, leaf_size=128, index_base=0):
+        """The same index through rt_dp_knn_tree_build_device (HIP kernels + one radix sort per level)."""
+        t = ctx.knn_tree_build_device(points, leaf_size, index_base)
+        self = cls.__new__(cls)
+        self.points, self.index, self.leaf_lo, self.leaf_hi = t["points"], t["index"], t["leaf_lo"], t["leaf_hi"]
+        self.n_leaves, self.leaf_size, self.n_points = t["n_leaves"], leaf_size, int(points.shape[0])
+        self.depth = max(0, self.n_leaves.bit_length() - 1)
+        # heap order -> one tensor per level, as home_leaf reads them
+        self.split_dim = [t["split_dim"][(1 << l) - 1:(2 << l) - 1].to(torch.int64) for l in range(self.depth)]
+        self.split_val = [t["split_val"][(1 << l) - 1:(2 << l) - 1] for l in range(self.depth)]
+        return self
+
     def home_leaf(self, queries):
         """The leaf each query falls into when it descends the split planes (int32 [m])."""
         seg = torch.zeros(queries.shape[0], dtype=torch.int64, device=queries.device)

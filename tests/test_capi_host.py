@@ -75,6 +75,8 @@ def test_argument_errors_without_a_device():
     assert L.rt_dp_box_compact(None, None, 1, None, None, None, None, None, 0, None) == capi.ENULL
     assert L.rt_dp_pairs_to_beats(None, None, None, None, None, 1, 1, 16, None, None, None, None) == capi.ENULL
     assert L.rt_dp_beats_to_pairs(None, None, None, 1, None, None) == capi.ENULL
+    assert L.rt_dp_knn_tree_build_device(None, None, 1, 4, 0, None, None, None, None, None, None) == capi.ENULL
+    assert L.rt_dp_knn_home_leaf(None, None, 1, 1, None, None, None, None) == capi.ENULL
     assert L.rt_dp_bvh4_build_device(None, None, 1, 4, None, None, None, None) == capi.ENULL
     assert L.rt_dp_set_option(None, b"variant", 0) == capi.ENULL
     assert L.rt_dp_set_tuning(None, 0, 0, 0) == capi.ENULL
