@@ -83,6 +83,9 @@ def soak_knn(rng, seed):
     tree = knn_tree.KnnTree(P, leaf_size=leaf, index_base=base)
     ok &= bool(torch.equal(knn_tree.local_topk(c, tree, Q, splits=None), want))
     ok &= bool(torch.equal(knn_tree.local_topk_grouped(c, tree, Q, walk_leaves=int(rng.choice([1, 8, 128]))), want))
+    dtree = knn_tree.KnnTree.build_device(c, P, leaf_size=leaf, index_base=base)   # the index built by the HIP builder
+    ok &= bool(torch.equal(knn_tree.local_topk(c, dtree, Q, splits=None), want))
+    ok &= bool(torch.equal(knn_tree.local_topk_grouped(c, dtree, Q, walk_leaves=int(rng.choice([1, 8, 128]))), want))
     ga = knn.local_topk_angular(c, P, Q, base, splits=int(rng.integers(1, 5)))
     ad, ai = O.knn_bruteforce_angular(pts, qry[sub], 16, base)
     gd, gi = knn.unpack_signed_keys(ga)
