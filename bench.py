@@ -31,6 +31,34 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def spawn_ranks():
+    """`python bench.py --gpus N` from a plain shell (no torchrun environment): start the N ranks as a CHILD
+    `python -m torch.distributed.run` and relay its output and exit code.  This runs before torch or the HIP
+    library is imported, so the parent never touches a GPU; it is a subprocess, never an exec."""
+    import socket
+    import subprocess
+    n = 1
+    argv = sys.argv[1:]
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1 or "WORLD_SIZE" in os.environ or "-h" in argv or "--help" in argv:
+        return
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    sys.exit(subprocess.call(cmd, env=dict(os.environ, RT_DP_BENCH_SPAWNED="1")))
+
+
+if __name__ == "__main__":
+    spawn_ranks()
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

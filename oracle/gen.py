@@ -1,4 +1,8 @@
-"""Deterministic synthetic operand streams for the four datapath opcodes.
+"""Deterministic synthetic operand streams for the four datapath opcodes, and the float32 restatement of the
+reference's ray derivation (ray_derived) that the ray pre-processing kernels are checked against.
+
+TEST INFRASTRUCTURE, like everything under oracle/: imported by tests/, the fixture generator and the smoke
+check only, never by the product package.
 
 Distributions follow the reference's own random generators
 (src/test/scala/raytracer_datapath/raytracer_gold/SW_Data.scala:310-417 and the

@@ -1,5 +1,5 @@
 """On-device synthetic operand streams for the benchmark (torch is only the
-allocator / RNG here).  Same distributions as raytracer_amd.gen, generated
+allocator / RNG here).  Same distributions as the host generators of the test suite (oracle/gen.py), generated
 directly in HBM so that a 2^24-op stream needs no host staging.
 
 Reference generators mirrored: src/test/scala/raytracer_datapath/raytracer_gold/

@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
 from oracle import dp_oracle as O  # noqa: E402
-from raytracer_amd import gen  # noqa: E402
+from oracle import gen  # noqa: E402
 
 u32, f32 = np.uint32, np.float32
 N = 100

@@ -1,10 +1,11 @@
-"""Per-call latency of the entry points on small batches (host and device pointers).  python scripts/latency.py"""
+"""Per-call latency of the entry points on small batches (host and device pointers).  python tests/soak/latency.py"""
 import sys, time, os
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
-from raytracer_amd import capi, gen
+from raytracer_amd import capi
+from oracle import gen
 from test_gpu_parity import _mixed_stream
 from helpers import hip_box
 c = capi.Context()

@@ -2,7 +2,7 @@
 """Parity soak: many seeded random + edge-case streams of every opcode through the C ABI against the
 scalar golden model (oracle B), bit for bit.  Not part of the test suite (minutes of run time):
 
-    python scripts/soak.py [seeds] [ops per stream]
+    python tests/soak/soak.py [seeds] [ops per stream]
 """
 import os
 import sys
@@ -10,11 +10,12 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import dp_oracle as O  # noqa: E402  (the checker)
-from raytracer_amd import capi, gen  # noqa: E402
+from raytracer_amd import capi  # noqa: E402
+from oracle import gen  # noqa: E402
 from helpers import hip_angular, hip_box, hip_euclid, hip_tri  # noqa: E402
 
 seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40

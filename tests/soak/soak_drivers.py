@@ -4,7 +4,7 @@ and in random pieces), the k-NN searches (exhaustive, tree walk, leaf-major; Euc
 closest-hit traversal (both walks) and the hit-mask compaction, each against the CPU oracle or a model built from
 it.  Not part of the test suite (minutes of run time):
 
-    python scripts/soak_drivers.py [rounds] [first seed]
+    python tests/soak/soak_drivers.py [rounds] [first seed]
 """
 import os
 import sys
@@ -12,11 +12,12 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import dp_oracle as O  # noqa: E402  (the checker)
-from raytracer_amd import bvh, capi, gen, knn, knn_tree  # noqa: E402
+from raytracer_amd import bvh, capi, knn, knn_tree  # noqa: E402
+from oracle import gen  # noqa: E402
 from test_gpu_parity import _mixed_stream  # noqa: E402
 from test_knn import clustered_cloud, make_cloud  # noqa: E402
 from test_box_compact import model as compact_model  # noqa: E402

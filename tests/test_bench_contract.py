@@ -51,3 +51,16 @@ def test_two_rank_rehearsal_line():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = check_line(r.stdout, 2, 3, 1)
     assert d["cpu_baseline"] is None and set(d["per_opcode"]) == {"box", "tri", "euclid", "angular", "mixed"}
+
+
+@pytest.mark.gpu
+def test_plain_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` from a plain shell (no torchrun on the command line, no rank environment): bench.py starts its
+    two ranks as a child process and relays rank 0's line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RT_DP_REHEARSE_ONE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--log2-ops", "20"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = check_line(r.stdout, 2, 3, 1)
+    assert d["cpu_baseline"] is None

@@ -4,7 +4,8 @@ wave and workgroup granularities."""
 import numpy as np
 import pytest
 
-from raytracer_amd import capi, gen
+from raytracer_amd import capi
+from oracle import gen
 
 from test_gpu_canaries import Guarded
 

@@ -102,7 +102,7 @@ def test_even_cuts_cover_everything():
 
 
 def test_vec_cuts_fall_on_pair_boundaries():
-    from raytracer_amd import gen
+    from oracle import gen
     _, _, ctl, _ = gen.vec_beats(5000, 16, seed=2)
     for w in (1, 2, 4, 8):
         cuts = shard.vec_cuts(ctl, w)

@@ -5,7 +5,8 @@ fed with the float32 restatement of SW_Ray (gen.ray_derived, SW_Data.scala:36-82
 import numpy as np
 import pytest
 
-from raytracer_amd import capi, gen
+from raytracer_amd import capi
+from oracle import gen
 
 from helpers import assert_bits_equal, hip_box, hip_tri
 

@@ -3,7 +3,8 @@ with a sentinel, for sizes around the kernels' wave / workgroup / tile granulari
 import numpy as np
 import pytest
 
-from raytracer_amd import bvh, capi, gen
+from raytracer_amd import bvh, capi
+from oracle import gen
 
 pytestmark = pytest.mark.gpu
 GUARD = 4096            # words on either side

@@ -6,7 +6,8 @@ raw 32-bit patterns: no tolerance anywhere.
 import numpy as np
 import pytest
 
-from raytracer_amd import capi, gen
+from raytracer_amd import capi
+from oracle import gen
 
 from helpers import assert_bits_equal, hip_angular, hip_box, hip_euclid, hip_tri
 

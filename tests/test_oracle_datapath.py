@@ -10,7 +10,7 @@
 import numpy as np
 import pytest
 
-from raytracer_amd import gen
+from oracle import gen
 
 import gold_model
 

@@ -1,10 +1,11 @@
 """Vector pairs <-> beats: rt_dp_beat_offsets_host against the splitter's beat counts on CPU; on the GPU the split
-equals the Python restatement of the reference's job splitters (raytracer_amd.gen.vec_beats, SW_Data.scala:213-308)
+equals the Python restatement of the reference's job splitters (oracle.gen.vec_beats, SW_Data.scala:213-308)
 word for word, and pairs -> beats -> distance op -> pair values equals the oracle run on that restatement."""
 import numpy as np
 import pytest
 
-from raytracer_amd import capi, gen
+from raytracer_amd import capi
+from oracle import gen
 
 f32, u32 = np.float32, np.uint32
 LENGTHS = np.array([1, 16, 17, 0, 8, 9, 128, 31, 32, 33, 0, 0, 5, 100, 64, 2], np.int64)

@@ -20,7 +20,8 @@ WORKER = r"""
 import os, sys
 import numpy as np
 sys.path.insert(0, %(root)r)
-from raytracer_amd import dist_util, gen, shard
+from raytracer_amd import dist_util, shard
+from oracle import gen
 from oracle import dp_oracle as O
 
 world, rank, local = dist_util.init("gloo")

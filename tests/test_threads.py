@@ -6,7 +6,8 @@ import threading
 import numpy as np
 import pytest
 
-from raytracer_amd import capi, gen
+from raytracer_amd import capi
+from oracle import gen
 
 from helpers import assert_bits_equal, hip_box, hip_euclid, hip_tri
 

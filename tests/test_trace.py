@@ -80,7 +80,7 @@ def test_trace_agrees_with_testing_every_triangle(ctx, oracle, torch_cuda, wavef
     nodes, tris12, order = bvh.build_bvh4(tris, leaf_size=4)
     org, dirs = bvh.rays_towards(tris, 400, seed=4, jitter=2.0)
     got_t, got_i, _ = run_gpu(ctx, torch_cuda, nodes, tris12, org, dirs, 4000.0, wavefront)
-    from raytracer_amd import gen
+    from oracle import gen
     inv, kx, ky, kz, shear = gen.ray_derived(dirs)
     kw = gen.pack_k(kx, ky, kz)
     r, t = np.repeat(np.arange(400), 600), np.tile(np.arange(600), 400)

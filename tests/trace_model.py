@@ -5,7 +5,8 @@ hit inner children form the next level; hit leaves run one triangle op per trian
 with t = t_num / t_denom (IEEE division, -0 read as +0, NaN ignored) competes by (t, triangle)."""
 import numpy as np
 
-from raytracer_amd import bvh, gen
+from raytracer_amd import bvh
+from oracle import gen
 
 f32, u32, u64 = np.float32, np.uint32, np.uint64
 BEST_NONE = u64(0x7F800000FFFFFFFF)
