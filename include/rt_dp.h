@@ -389,6 +389,22 @@ int rt_dp_knn_tree_grouped_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, 
 int rt_dp_box_compact(rt_dp_ctx *ctx, const rt_dp_box_out *results, uint64_t n, const uint32_t *item, const uint32_t *children,
                       uint32_t *out_item, uint32_t *out_child, float *out_tmin, uint64_t capacity, uint64_t *count);
 
+/* The same compaction with no allocation anywhere on the call path.  It has no counterpart in the
+ * reference; it exists for callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  The block counts and offsets that
+ * rt_dp_box_compact keeps in a buffer the context grows live here in a fixed array inside the library
+ * (768 KiB per GPU, held until the process ends), so n is limited to RT_DP_BOX_COMPACT_STATIC_MAX_OPS
+ * per call (RT_DP_EINVAL beyond).  Arguments as for rt_dp_box_compact, except that the number of
+ * entries goes to *d_count in DEVICE memory (8-byte aligned) and nothing is copied to the host: the
+ * call only enqueues kernels on `hip_stream` (NULL = context stream) and returns; ordering against the
+ * producer of the results is the caller's.  All calls on one GPU share the array: calls that overlap
+ * on one GPU (two streams, two contexts, two threads) race; calls in sequence on one stream are safe,
+ * and nothing in the array has to be cleared between them.                                        */
+#define RT_DP_BOX_COMPACT_STATIC_MAX_OPS (1u << 24)
+int rt_dp_box_compact_static(rt_dp_ctx *ctx, const rt_dp_box_out *results, uint64_t n, const uint32_t *item, const uint32_t *children,
+                             uint32_t *out_item, uint32_t *out_child, float *out_tmin, uint64_t capacity, uint64_t *d_count,
+                             void *hip_stream);
+
 /* ---- closest-hit traversal on the Quadbox and triangle ops ----------------------------
  * No counterpart in the reference's sources, which end at the datapath: this is the loop a
  * consumer runs around it.  The ops are those of UnifiedDatapath.scala (children sorted by

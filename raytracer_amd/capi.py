@@ -124,7 +124,7 @@ class KnnTree(C.Structure):
                 ("points", C.c_void_p), ("index", C.c_void_p), ("leaf_lo", C.c_void_p), ("leaf_hi", C.c_void_p)]
 
 EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize",
-           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_knn_angular16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_box_compact", "rt_dp_beat_offsets_host", "rt_dp_pairs_to_beats", "rt_dp_beats_to_pairs", "rt_dp_bvh4_build_device", "rt_dp_knn_tree_build_device", "rt_dp_knn_home_leaf", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
+           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_knn_euclid16", "rt_dp_knn_angular16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_box_compact", "rt_dp_box_compact_static", "rt_dp_beat_offsets_host", "rt_dp_pairs_to_beats", "rt_dp_beats_to_pairs", "rt_dp_bvh4_build_device", "rt_dp_knn_tree_build_device", "rt_dp_knn_home_leaf", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
            "rt_dp_knn_tree_leaves", "rt_dp_knn_tree_build_host", "rt_dp_knn_home_leaf_host", "rt_dp_bvh4_max_nodes", "rt_dp_bvh4_build_host",
            "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
 
@@ -175,6 +175,7 @@ def load():
     L.rt_dp_knn_tree_build_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp]
     L.rt_dp_knn_home_leaf.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     L.rt_dp_box_compact.argtypes = [vp, C.POINTER(BoxOut), C.c_uint64, vp, vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.rt_dp_box_compact_static.argtypes = [vp, C.POINTER(BoxOut), C.c_uint64, vp, vp, vp, vp, vp, C.c_uint64, vp, vp]
     L.rt_dp_trace_closest.argtypes = [vp, C.POINTER(Bvh4), C.POINTER(vp * 3), C.POINTER(vp * 3), C.c_uint32, C.c_float, C.c_uint32, vp, vp,
                                       C.POINTER(C.c_uint64 * 4)]
     L.rt_dp_knn_tree_leaves.argtypes = [C.c_uint32, C.c_uint32]
@@ -441,6 +442,20 @@ class Context:
         _check(self._L.rt_dp_box_compact(self._h, C.byref(ro), n, p(item), p(children), p(out_item), p(out_child), p(out_tmin),
                                          int(out_item.shape[0]), C.byref(count)))
         return int(count.value)
+
+    def box_compact_static(self, tmin, flags, out_item, out_child, d_count, out_tmin=None, item=None, children=None, n=None, stream=None):
+        """rt_dp_box_compact_static: as box_compact, but allocation-free and asynchronous; d_count is an int64 CUDA
+        tensor of one element that receives the number of entries.  n defaults to flags.shape[0]."""
+        ro = BoxOut()
+        keep = set()
+        if tmin is not None:
+            for k in range(4):
+                ro.tmin_out[k] = _ptr(tmin[k], keep)
+        ro.flags = _ptr(flags, keep)
+        p = lambda t: None if t is None else t.data_ptr()
+        _check(self._L.rt_dp_box_compact_static(self._h, C.byref(ro), int(flags.shape[0]) if n is None else int(n), p(item), p(children),
+                                                p(out_item), p(out_child), p(out_tmin), int(out_item.shape[0]), p(d_count),
+                                                C.c_void_p(stream) if stream else None))
 
     def pairs_to_beats(self, a, b, pair_offsets, width):
         """Vector pairs (flat float32 CUDA tensors a, b; pair_offsets: int64 numpy array [n_pairs + 1]) split into

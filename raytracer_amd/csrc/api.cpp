@@ -362,6 +362,7 @@ int rt_dp_create(const rt_dp_config *cfg, rt_dp_ctx **out) {
     ctx->tuning.vec_passes = env_int("RT_DP_VEC_PASSES", 0);
     ctx->tuning.wgs_per_cu = env_int("RT_DP_WGS_PER_CU", 0);
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = compact_static_init(dev);  // address of this GPU's copy of the allocation-free entry point's scratch
     if (e == hipSuccess) e = hipMalloc(&ctx->d_state, 12 * sizeof(float));
     if (e == hipSuccess) e = hipMemsetAsync(ctx->d_state, 0, 12 * sizeof(float), ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -903,6 +904,37 @@ int rt_dp_box_compact(rt_dp_ctx *ctx, const rt_dp_box_out *results, uint64_t n, 
     HIP_TRY(hipMemcpyAsync(&h, total, sizeof h, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     *count = h;
+    return RT_DP_OK;
+}
+
+// rt_dp_box_compact for callers that cannot allocate: offsets in a file-scope device array (compact.hip), the
+// count delivered to device memory, nothing but kernel launches (and one memset for an empty batch) on the path.
+int rt_dp_box_compact_static(rt_dp_ctx *ctx, const rt_dp_box_out *results, uint64_t n, const uint32_t *item, const uint32_t *children,
+                             uint32_t *out_item, uint32_t *out_child, float *out_tmin, uint64_t capacity, uint64_t *d_count, void *hip_stream) {
+    if (!ctx || !results || !d_count) return fail(RT_DP_ENULL, "rt_dp_box_compact_static: NULL argument");
+    if (n > compact_static_max_ops())
+        return fail(RT_DP_EINVAL, "rt_dp_box_compact_static: n = %llu exceeds the static scratch (at most %llu ops per call); use rt_dp_box_compact",
+                    (unsigned long long)n, (unsigned long long)compact_static_max_ops());
+    if (reinterpret_cast<uintptr_t>(d_count) & 7u) return fail(RT_DP_EALIGN, "rt_dp_box_compact_static: d_count must be 8-byte aligned");
+    if (n && (!results->flags || (capacity && (!out_item || !out_child)))) return fail(RT_DP_ENULL, "rt_dp_box_compact_static: NULL array");
+    uintptr_t acc = reinterpret_cast<uintptr_t>(results->flags) | reinterpret_cast<uintptr_t>(item) | reinterpret_cast<uintptr_t>(children) |
+                    reinterpret_cast<uintptr_t>(out_item) | reinterpret_cast<uintptr_t>(out_child) | reinterpret_cast<uintptr_t>(out_tmin);
+    if (n && out_tmin)
+        for (int k = 0; k < 4; ++k) {
+            if (!results->tmin_out[k]) return fail(RT_DP_ENULL, "rt_dp_box_compact_static: out_tmin needs all four tmin_out arrays");
+            acc |= reinterpret_cast<uintptr_t>(results->tmin_out[k]);
+        }
+    if (n && (acc & 3u)) return fail(RT_DP_EALIGN, "rt_dp_box_compact_static: arrays must be 4-byte aligned");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream;
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint64_t), s));
+        return RT_DP_OK;
+    }
+    const float *tm[4] = {results->tmin_out[0], results->tmin_out[1], results->tmin_out[2], results->tmin_out[3]};
+    HIP_TRY(compact_hits_static(ctx->device, results->flags, tm, n, item, children, capacity, out_item, out_child, out_tmin,
+                                reinterpret_cast<unsigned long long *>(d_count), s));
     return RT_DP_OK;
 }
 

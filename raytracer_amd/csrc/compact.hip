@@ -11,6 +11,8 @@
 // The list is a pure function of the inputs (no atomics decide the order).
 #include "kernels.h"
 
+#include <mutex>
+
 namespace rtdp {
 
 constexpr int kCmpBlk = 256;
@@ -94,6 +96,49 @@ hipError_t compact_hits(const uint32_t *flags, const float *const tmin[4], uint6
     hipLaunchKernelGGL(k_compact_emit, dim3((unsigned)nblk), dim3(kCmpBlk), 0, s, flags, tmin[0], tmin[1], tmin[2], tmin[3], n, item,
                        children, offsets64, capacity, out_item, out_child, out_tmin);
     return hipGetLastError();
+}
+
+// ---- the same compaction for callers that cannot allocate -----------------------------------------------
+// The block counts and offsets live in a file-scope device array instead of a buffer the context grows, so the
+// call path contains no allocation at all.  Every GPU holds its own copy of the array at its own address: the
+// address is looked up once per device (compact_static_init, with that device current) and kept; host code
+// never uses the array's name for anything else.  Nothing in the array has to start at zero: a call writes
+// every count and offset it reads.  Calls that overlap on one GPU share the array and race.
+constexpr uint64_t kStaticMaxOps = 1ull << 24;
+constexpr uint64_t kStaticBlocks = kStaticMaxOps / kCmpBlk;
+static __device__ __align__(256) unsigned char scratch[kStaticBlocks * 12];  // [blocks] u64 offsets, then [blocks] u32 counts: 768 KiB
+
+constexpr int kMaxDevices = 64;
+static unsigned char *g_scratch_ptr[kMaxDevices];
+static std::mutex g_scratch_lock;
+
+uint64_t compact_static_max_ops() { return kStaticMaxOps; }
+
+hipError_t compact_static_init(int device) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> hold(g_scratch_lock);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    void *p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    g_scratch_ptr[device] = static_cast<unsigned char *>(p);
+    return hipSuccess;
+}
+
+hipError_t compact_hits_static(int device, const uint32_t *flags, const float *const tmin[4], uint64_t n, const uint32_t *item,
+                               const uint32_t *children, uint64_t capacity, uint32_t *out_item, uint32_t *out_child, float *out_tmin,
+                               unsigned long long *d_count, hipStream_t s) {
+    if (device < 0 || device >= kMaxDevices || n > kStaticMaxOps) return hipErrorInvalidValue;
+    unsigned char *base;
+    {
+        std::lock_guard<std::mutex> hold(g_scratch_lock);
+        base = g_scratch_ptr[device];
+    }
+    if (!base) return hipErrorNotInitialized;
+    unsigned long long *offsets64 = reinterpret_cast<unsigned long long *>(base);
+    uint32_t *blockcnt = reinterpret_cast<uint32_t *>(base + kStaticBlocks * 8);
+    return compact_hits(flags, tmin, n, item, children, blockcnt, offsets64, d_count, capacity, out_item, out_child, out_tmin, s);
 }
 
 }  // namespace rtdp

@@ -88,6 +88,14 @@ hipError_t compact_hits(const uint32_t *flags, const float *const tmin[4], uint6
                         uint32_t *blockcnt, unsigned long long *offsets64, unsigned long long *total, uint64_t capacity, uint32_t *out_item,
                         uint32_t *out_child, float *out_tmin, hipStream_t s);
 
+// the same with the offsets in a file-scope device array (no allocation on the call path): compact_static_init once per
+// device with that device current, then compact_hits_static; *d_count (device memory) receives the number of entries
+uint64_t compact_static_max_ops();
+hipError_t compact_static_init(int device);
+hipError_t compact_hits_static(int device, const uint32_t *flags, const float *const tmin[4], uint64_t n, const uint32_t *item,
+                               const uint32_t *children, uint64_t capacity, uint32_t *out_item, uint32_t *out_child, float *out_tmin,
+                               unsigned long long *d_count, hipStream_t s);
+
 // vector pairs <-> beats (pairs.hip)
 hipError_t pairs_to_beats(const float *a, const float *b, const uint64_t *pair_offsets, const uint64_t *beat_offsets, uint64_t n_pairs,
                           uint64_t n_beats, uint32_t width, float *out_a, float *out_b, uint32_t *out_ctl, hipStream_t s);
