@@ -78,6 +78,8 @@ def parse():
     p.add_argument("--ops", type=int, default=0, help="ops per GPU when not a power of two (overrides --log2-ops)")
     p.add_argument("--stagger-kib", type=int, default=0, help="box workload: operand arrays live in one allocation, array k shifted by k x this many KiB "
                                                               "beyond its natural place, so that the arrays do not cross page boundaries together")
+    p.add_argument("--launch-ops", type=int, default=0, help="box workload, diagnostic: launch only the first this-many ops of the resident arrays "
+                                                              "(the arrays keep their size and spacing)")
     p.add_argument("--ops-per-lane", type=int, default=0)
     p.add_argument("--nontemporal", type=int, default=0)
     p.add_argument("--vec-tile", type=int, default=0)
@@ -109,7 +111,7 @@ def parse():
     return p.parse_args()
 
 
-def make_batches(n, dev, which, stagger_kib=0, derive=False):
+def make_batches(n, dev, which, stagger_kib=0, derive=False, launch_ops=0):
     """Resident operand / result arrays and one capi.Batch per workload."""
     out = {}
     i32, f32 = torch.int32, torch.float32
@@ -146,9 +148,9 @@ def make_batches(n, dev, which, stagger_kib=0, derive=False):
     if "box" in which:
         b = capi.Batch().derive_ray(derive)
         fields, tmin, flags = box(n)
-        b.set_box(fields, tmin, flags)
+        b.set_box(fields, tmin, flags, launch_ops or None)
         b.box_fields = fields
-        out["box"] = (b.finalize(), {"box": n})
+        out["box"] = (b.finalize(), {"box": launch_ops or n})
     if "tri" in which:
         b = capi.Batch().derive_ray(derive)   # derive: the three shear arrays stand in for the ray direction
         b.set_tri(*tri(n))
@@ -520,7 +522,7 @@ def main():
     ctx.set_option("wgs_per_cu", a.wgs_per_cu)
     if a.derive:
         BYTES.update(box=144, tri=72)
-    batches = make_batches(n, dev, which, a.stagger_kib, bool(a.derive))
+    batches = make_batches(n, dev, which, a.stagger_kib, bool(a.derive), a.launch_ops)
     torch.cuda.synchronize()
 
     if a.sweep:

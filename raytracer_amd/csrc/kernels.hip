@@ -222,40 +222,71 @@ __device__ __forceinline__ float quad_xor2(float v) {  // quad_perm [2,3,0,1]
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
 }
 
-// First pair boundary at or after `nominal` (a beat index whose predecessor
-// carries the reset bit), n if there is none.  Executed by one full wave.
-__device__ __forceinline__ uint64_t pair_boundary(const uint32_t *ctl, uint64_t nominal, uint64_t n, int lane) {
+// First pair boundary (a beat index whose predecessor carries the reset bit; 0 and n count as boundaries) at or
+// after `nominal`, looked for in windows of 64 beats that start below `limit`; a value >= limit means that no
+// boundary lies in [nominal, limit).  Executed by one full wave; at most (limit - nominal) / 64 + 1 loads per lane.
+__device__ __forceinline__ uint64_t pair_boundary(const uint32_t *ctl, uint64_t nominal, uint64_t limit, uint64_t n, int lane) {
     if (nominal == 0) return 0;
     if (nominal >= n) return n;
-    for (uint64_t i0 = nominal;; i0 += 64) {  // terminates: indices >= n act as boundaries
+    for (uint64_t i0 = nominal; i0 < limit; i0 += 64) {
         const uint64_t i = i0 + lane;
-        const bool p = (i < n) ? (((ctl[i - 1] >> 16) & 1u) != 0u) : true;
+        const bool p = (i < n) ? (((ctl[i - 1] >> 16) & 1u) != 0u) : true;  // indices >= n act as boundaries
         const unsigned long long m = __ballot(p);
         if (m) {
             const uint64_t r = i0 + (uint64_t)(__ffsll((long long)m) - 1);
             return r < n ? r : n;
         }
     }
+    return limit < n ? limit : n;  // not a boundary: only "none below limit"
 }
 
-template <bool EUC, bool NT, int PASSES>
+// The same without a limit, for the end of a vector pair that runs on beyond the tile after the one it started
+// in: 512 beats per round with eight loads in flight per lane, so the search costs a small fraction of the serial
+// accumulation the same workgroup then performs over those beats.  Terminates at n.
+__device__ __forceinline__ uint64_t pair_boundary_far(const uint32_t *ctl, uint64_t start, uint64_t n, int lane) {
+    if (start >= n) return n;
+    for (uint64_t i0 = start;; i0 += 512) {
+        bool p[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint64_t i = i0 + (uint64_t)k * 64 + lane;
+            p[k] = (i < n) ? (((ctl[i - 1] >> 16) & 1u) != 0u) : true;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned long long m = __ballot(p[k]);
+            if (m) {
+                const uint64_t r = i0 + (uint64_t)k * 64 + (uint64_t)(__ffsll((long long)m) - 1);
+                return r < n ? r : n;
+            }
+        }
+    }
+}
+
+template <bool EUC, bool NT, int PASSES, int WALK>
 __global__ __launch_bounds__(256) void k_vec(VecArgs args, uint64_t n, uint32_t tile) {
     constexpr int LPB = EUC ? 4 : 2;         // lanes per beat
     constexpr int BPP = kThreads / LPB;      // beats per pass
     constexpr int SUB = PASSES * BPP;        // beats per sub-tile
     constexpr int ROW = EUC ? 16 : 8;        // floats per beat and vector
 
-    __shared__ float s_sum0[SUB];
-    __shared__ float s_sum1[EUC ? 1 : SUB];
-    __shared__ uint32_t s_ctl[SUB];
-    __shared__ float s_out0[SUB];
-    __shared__ float s_out1[EUC ? 1 : SUB];
+    __shared__ float s_sum0[SUB + WALK];
+    __shared__ float s_sum1[EUC ? 1 : SUB + WALK];
+    __shared__ uint32_t s_ctl[SUB + WALK];
+    __shared__ float s_out0[SUB + WALK];
+    __shared__ float s_out1[EUC ? 1 : SUB + WALK];
     __shared__ uint64_t s_range[2];
     __shared__ float s_carry[2][2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // This workgroup owns the vector pairs that START in its nominal range [first, next).  Both searches are
+    // limited to one tile: a workgroup whose range holds no pair start leaves after tile / 64 loads per lane
+    // however long the pair that covers it is, and only a workgroup that owns a long pair looks further for
+    // its end -- over beats it then has to accumulate one by one anyway.
+    const uint64_t first = (uint64_t)blockIdx.x * tile, next = first + tile;
     if (wave < 2) {
-        const uint64_t r = pair_boundary(args.ctl, (uint64_t)(blockIdx.x + wave) * tile, n, lane);
+        const uint64_t from = wave ? next : first;
+        const uint64_t r = pair_boundary(args.ctl, from, from + tile, n, lane);
         if (lane == 0) s_range[wave] = r;
     }
     if (tid == 0) {
@@ -264,8 +295,18 @@ __global__ __launch_bounds__(256) void k_vec(VecArgs args, uint64_t n, uint32_t 
         s_carry[0][1] = (!EUC && blockIdx.x == 0) ? args.state_in[1] : 0.0f;
     }
     __syncthreads();
-    const uint64_t lo = s_range[0], hi = s_range[1];
-    if (lo >= hi) return;
+    const uint64_t lo = s_range[0];
+    if (lo >= next || lo >= n) return;  // no pair starts here
+    uint64_t hi = s_range[1];
+    if (hi < n && hi >= next + tile) {  // the last pair that starts here runs on beyond the next tile (uniform branch)
+        __syncthreads();
+        if (wave == 0) {
+            const uint64_t r = pair_boundary_far(args.ctl, hi, n, lane);
+            if (lane == 0) s_range[1] = r;
+        }
+        __syncthreads();
+        hi = s_range[1];
+    }
 
     const int part = tid % LPB;  // which four elements of the beat
     int par = 0;
@@ -326,29 +367,47 @@ __global__ __launch_bounds__(256) void k_vec(VecArgs args, uint64_t n, uint32_t 
         }
         __syncthreads();
 
-        // phase 2: one lane per vector pair accumulates its beats in order
+        // phase 2: one lane per vector pair accumulates its beats in order.  The chain acc -> acc + sum is serial
+        // by definition, but the sums and control words do not depend on it: WALK of them are fetched from LDS per
+        // round trip (the arrays are padded, so the look-ahead past a pair's end or past cnt stays in bounds and
+        // is simply not used).
         for (int t0 = tid; t0 < cnt; t0 += kThreads) {
             const bool starts = (t0 == 0) || (((s_ctl[t0 - 1] >> 16) & 1u) != 0u);
             if (starts) {
                 float acc0 = (t0 == 0) ? s_carry[par][0] : 0.0f;
                 float acc1 = (t0 == 0) ? s_carry[par][1] : 0.0f;
                 int i = t0;
-                bool rs;
-                do {
-                    const float o0 = acc0 + s_sum0[i];
-                    s_out0[i] = canon_nan(o0);
-                    rs = ((s_ctl[i] >> 16) & 1u) != 0u;
-                    acc0 = rs ? 0.0f : o0;
-                    if (!EUC) {
-                        const float o1 = acc1 + s_sum1[i];
-                        s_out1[i] = canon_nan(o1);
-                        acc1 = rs ? 0.0f : o1;
+                bool more = true;
+                while (more) {
+                    float v0[WALK], v1[WALK];
+                    uint32_t c[WALK];
+#pragma unroll
+                    for (int k = 0; k < WALK; ++k) {
+                        v0[k] = s_sum0[i + k];
+                        if (!EUC) v1[k] = s_sum1[i + k];
+                        c[k] = s_ctl[i + k];
                     }
-                    ++i;
-                } while (i < cnt && !rs);
-                if (i == cnt) {  // exactly one lane reaches the end of the sub-tile
-                    s_carry[par ^ 1][0] = acc0;
-                    s_carry[par ^ 1][1] = acc1;
+#pragma unroll
+                    for (int k = 0; k < WALK; ++k) {
+                        if (more) {
+                            const bool rs = ((c[k] >> 16) & 1u) != 0u;
+                            const float o0 = acc0 + v0[k];
+                            s_out0[i + k] = canon_nan(o0);
+                            acc0 = rs ? 0.0f : o0;
+                            if (!EUC) {
+                                const float o1 = acc1 + v1[k];
+                                s_out1[i + k] = canon_nan(o1);
+                                acc1 = rs ? 0.0f : o1;
+                            }
+                            const bool last = (i + k + 1 == cnt);
+                            if (last) {  // exactly one lane reaches the end of the sub-tile
+                                s_carry[par ^ 1][0] = acc0;
+                                s_carry[par ^ 1][1] = acc1;
+                            }
+                            more = !rs && !last;
+                        }
+                    }
+                    i += WALK;
                 }
             }
         }
@@ -518,13 +577,19 @@ hipError_t launch_tri(const TriArgs &args, uint64_t n, const Tuning &t, hipStrea
     return hipGetLastError();
 }
 
-template <bool EUC, bool NT> static void launch_vec_p(const VecArgs &args, uint64_t n, uint32_t tile, int passes, unsigned blocks, unsigned lds,
-                                                      hipStream_t stream) {
+template <bool EUC, bool NT, int WALK> static void launch_vec_w(const VecArgs &args, uint64_t n, uint32_t tile, int passes, unsigned blocks, unsigned lds,
+                                                                hipStream_t stream) {
     switch (passes) {
-    case 2: hipLaunchKernelGGL((k_vec<EUC, NT, 2>), dim3(blocks), dim3(kThreads), lds, stream, args, n, tile); break;
-    case 8: hipLaunchKernelGGL((k_vec<EUC, NT, 8>), dim3(blocks), dim3(kThreads), lds, stream, args, n, tile); break;
-    default: hipLaunchKernelGGL((k_vec<EUC, NT, 4>), dim3(blocks), dim3(kThreads), lds, stream, args, n, tile); break;
+    case 2: hipLaunchKernelGGL((k_vec<EUC, NT, 2, WALK>), dim3(blocks), dim3(kThreads), lds, stream, args, n, tile); break;
+    case 8: hipLaunchKernelGGL((k_vec<EUC, NT, 8, WALK>), dim3(blocks), dim3(kThreads), lds, stream, args, n, tile); break;
+    default: hipLaunchKernelGGL((k_vec<EUC, NT, 4, WALK>), dim3(blocks), dim3(kThreads), lds, stream, args, n, tile); break;
     }
+}
+
+template <bool EUC, bool NT> static void launch_vec_p(const VecArgs &args, uint64_t n, uint32_t tile, int passes, int walk, unsigned blocks, unsigned lds,
+                                                      hipStream_t stream) {
+    if (walk == 1) launch_vec_w<EUC, NT, 1>(args, n, tile, passes, blocks, lds, stream);
+    else launch_vec_w<EUC, NT, 4>(args, n, tile, passes, blocks, lds, stream);
 }
 
 template <bool EUC> static hipError_t launch_vec(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream) {
@@ -536,8 +601,9 @@ template <bool EUC> static hipError_t launch_vec(const VecArgs &args, uint64_t n
     const uint64_t blocks = (n + tile - 1) / tile;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const unsigned lds = residency_lds(t.wgs_per_cu, kVecWgsPerCu, 8192u);  // the kernel's own LDS stays below 8 KiB
-    if (use_nt(t)) launch_vec_p<EUC, true>(args, n, tile, passes, (unsigned)blocks, lds, stream);
-    else launch_vec_p<EUC, false>(args, n, tile, passes, (unsigned)blocks, lds, stream);
+    const int walk = (t.variant == 21) ? 1 : 4;  // variant 21 (A/B only): one LDS round trip per beat of the serial walk
+    if (use_nt(t)) launch_vec_p<EUC, true>(args, n, tile, passes, walk, (unsigned)blocks, lds, stream);
+    else launch_vec_p<EUC, false>(args, n, tile, passes, walk, (unsigned)blocks, lds, stream);
     return hipGetLastError();
 }
 

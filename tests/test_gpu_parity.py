@@ -170,6 +170,52 @@ def test_vec_no_reset_anywhere(ctx, oracle, torch_cuda):
     check_euclid(ctx, oracle, a, b, ctl, True, torch_cuda, acc0=1.0)
 
 
+@pytest.mark.parametrize("width", [16, 8])
+@pytest.mark.parametrize("pair_beats", [1 << 22, 1 << 18])
+def test_vec_reset_poor_streams_are_not_a_cliff(ctx, oracle, torch_cuda, width, pair_beats):
+    """2^22 beats with no reset at all (one endless pair) and with a reset every 2^18 beats: the workgroups whose
+    nominal range holds no pair start must leave after looking at their own tile only (the accumulation itself is
+    serial by definition and belongs to the workgroup in whose range the pair starts).  Bit-exact against the
+    oracle, and the launch stays under one second of wall time (measured on MI355X: tens of milliseconds)."""
+    import time
+    torch = torch_cuda
+    nb = 1 << 22
+    rng = np.random.default_rng(width + pair_beats)
+    a = (rng.random((nb, width), dtype=f32) * f32(200) - f32(100)).astype(f32)
+    b = (rng.random((nb, width), dtype=f32) * f32(200) - f32(100)).astype(f32)
+    ctl = np.full(nb, (1 << width) - 1, u32)
+    if pair_beats < nb:
+        ctl[pair_beats - 1::pair_beats] |= u32(1 << 16)
+        ctl[-1] &= u32(0xFFFF)                      # the last pair runs on into the next batch
+    da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    dc = torch.from_numpy(ctl.view(np.int32)).cuda()
+    out0 = torch.empty(nb, dtype=torch.float32, device="cuda")
+    out1 = torch.empty(nb, dtype=torch.float32, device="cuda")
+    bt = capi.Batch()
+    if width == 16:
+        bt.set_euclid(da, db, dc, out0, nb)
+    else:
+        bt.set_angular(da, db, dc, out0, out1, nb)
+    ctx.set_accum([0.5, -2.0, 3.0])
+    ctx.eval(bt)                                     # first call: code object load and the like
+    ctx.set_accum([0.5, -2.0, 3.0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.eval(bt)
+    wall = time.perf_counter() - t0
+    if width == 16:
+        want, acc = oracle.euclid_beats(a, b, ctl, 0.5)
+        assert_bits_equal(out0.cpu().numpy(), want, "euclidean_accumulator")
+        assert_bits_equal(ctx.get_accum()[0:1], np.array([acc], f32), "euclidean register after the batch")
+    else:
+        wd, wn, sd, sn = oracle.angular_beats(a, b, ctl, -2.0, 3.0)
+        assert_bits_equal(out0.cpu().numpy(), wd, "angular_dot_product")
+        assert_bits_equal(out1.cpu().numpy(), wn, "angular_norm")
+        assert_bits_equal(ctx.get_accum()[1:3], np.array([sd, sn], f32), "angular registers after the batch")
+    assert wall < 1.0, "reset-poor stream took %.3f s" % wall
+    print("reset-poor stream, width %d, pair of %d beats: %.1f ms" % (width, pair_beats, wall * 1e3))
+
+
 def test_accumulators_run_across_batches(ctx, oracle, torch_cuda):
     """Splitting a stream into several calls gives the same results as one call."""
     a, b, ctl, _ = gen.vec_beats(400, 16, seed=34)
