@@ -66,6 +66,10 @@ struct rt_dp_ctx {
     // leaf-major k-NN: per-query / per-leaf tables, the (leaf, query) lists, the candidate slots
     char *d_knn[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t knn_bytes[4] = {0, 0, 0, 0};
+    // rt_dp_launch on a caller stream: this event is recorded behind the batch, and everything that touches the
+    // accumulator registers on the context's own stream (or from the host) waits for it first
+    hipEvent_t launched = nullptr;
+    bool launched_pending = false;
     Tuning tuning{0, 0, 0, 0, 0, 0};
     int stream_mode = 0;  // record streams in HBM: 0 automatic, 1 partition by opcode first, 2 fused single pass
 };
@@ -134,6 +138,12 @@ int check_batch(const rt_dp_op_batch *in, const rt_dp_result_batch *out) {
         NEED(out->ang.norm, "result ang.norm");
     }
 #undef NEED
+    if (in->flags & RT_DP_F_DEVICE_PTRS) {  // host arrays are staged into aligned device buffers
+        if (in->n[RT_DP_OP_EUCLIDEAN] && ((reinterpret_cast<uintptr_t>(in->euc.a) | reinterpret_cast<uintptr_t>(in->euc.b)) & 15u))
+            return fail(RT_DP_EALIGN, "euc.a / euc.b must be 16-byte aligned device pointers");
+        if (in->n[RT_DP_OP_ANGULAR] && ((reinterpret_cast<uintptr_t>(in->ang.a) | reinterpret_cast<uintptr_t>(in->ang.b)) & 15u))
+            return fail(RT_DP_EALIGN, "ang.a / ang.b must be 16-byte aligned device pointers");
+    }
     return RT_DP_OK;
 }
 
@@ -161,6 +171,18 @@ void fill_tri(TriArgs &a, const rt_dp_tri_in &in, const rt_dp_tri_out &out, bool
     a.hit = out.hit;
 }
 
+// Orders the context's own stream (and, with host_too, the calling thread) behind the last batch that was
+// launched on a caller stream.
+int join_caller_stream(rt_dp_ctx *ctx, bool host_too) {
+    if (!ctx->launched_pending) return RT_DP_OK;
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->launched, 0));
+    if (host_too) {
+        HIP_TRY(hipEventSynchronize(ctx->launched));
+        ctx->launched_pending = false;
+    }
+    return RT_DP_OK;
+}
+
 // Enqueue the kernels of one batch whose arrays are all device pointers.
 int launch_device(rt_dp_ctx *ctx, const rt_dp_op_batch *in, const rt_dp_result_batch *out, hipStream_t s) {
     const uint64_t n_tri = in->n[RT_DP_OP_TRIANGLE], n_box = in->n[RT_DP_OP_QUADBOX];
@@ -186,11 +208,7 @@ int launch_device(rt_dp_ctx *ctx, const rt_dp_op_batch *in, const rt_dp_result_b
         }
         return RT_DP_OK;
     }
-    if (n_euc || n_ang) {
-        if (n_euc && ((reinterpret_cast<uintptr_t>(in->euc.a) | reinterpret_cast<uintptr_t>(in->euc.b)) & 15u))
-            return fail(RT_DP_EALIGN, "euc.a / euc.b must be 16-byte aligned device pointers");
-        if (n_ang && ((reinterpret_cast<uintptr_t>(in->ang.a) | reinterpret_cast<uintptr_t>(in->ang.b)) & 15u))
-            return fail(RT_DP_EALIGN, "ang.a / ang.b must be 16-byte aligned device pointers");
+    if (n_euc || n_ang) {  // (16-byte alignment of a / b: check_batch, before anything was enqueued)
         float *cur = ctx->d_state + 4 * ctx->cur, *nxt = ctx->d_state + 4 * (ctx->cur ^ 1);
         // registers of an opcode without beats in this batch are carried over unchanged
         HIP_TRY(hipMemcpyAsync(nxt, cur, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -294,10 +312,19 @@ int eval_host(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *out)
         for (auto &s : ins) memcpy(ctx->h_stage + s.off, s.src, s.bytes);
         if (in_total) HIP_TRY(hipMemcpyAsync(ctx->d_stage, ctx->h_stage, in_total, hipMemcpyHostToDevice, ctx->stream));
     } else {
-        for (auto &s : ins) HIP_TRY(hipMemcpyAsync(ctx->d_stage + s.off, s.src, s.bytes, hipMemcpyHostToDevice, ctx->stream));
+        for (auto &s : ins) {
+            hipError_t e = hipMemcpyAsync(ctx->d_stage + s.off, s.src, s.bytes, hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) {
+                (void)hipStreamSynchronize(ctx->stream);
+                return fail(RT_DP_EHIP, "staging copy failed: %s", hipGetErrorString(e));
+            }
+        }
     }
     int rc = launch_device(ctx, &din, &dout, ctx->stream);
-    if (rc != RT_DP_OK) return rc;
+    if (rc != RT_DP_OK) {
+        (void)hipStreamSynchronize(ctx->stream);  // the staged copies must not outlive the call: the next one reuses the buffers
+        return rc;
+    }
     if (pinned) {
         if (out_total) HIP_TRY(hipMemcpyAsync(ctx->h_stage + in_total, ctx->d_stage + in_total, out_total, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -309,7 +336,14 @@ int eval_host(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *out)
     return RT_DP_OK;
 }
 
-thread_local rt_dp_ctx *g_default_ctx = nullptr;
+// rt_dp_eval's per-thread default context; destroyed when its thread ends
+struct DefaultCtx {
+    rt_dp_ctx *p = nullptr;
+    ~DefaultCtx() {
+        if (p) rt_dp_destroy(p);
+    }
+};
+thread_local DefaultCtx g_default_ctx;
 
 }  // namespace
 
@@ -362,6 +396,7 @@ int rt_dp_create(const rt_dp_config *cfg, rt_dp_ctx **out) {
     ctx->tuning.vec_passes = env_int("RT_DP_VEC_PASSES", 0);
     ctx->tuning.wgs_per_cu = env_int("RT_DP_WGS_PER_CU", 0);
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->launched, hipEventDisableTiming);
     if (e == hipSuccess) e = compact_static_init(dev);  // address of this GPU's copy of the allocation-free entry point's scratch
     if (e == hipSuccess) e = hipMalloc(&ctx->d_state, 12 * sizeof(float));
     if (e == hipSuccess) e = hipMemsetAsync(ctx->d_state, 0, 12 * sizeof(float), ctx->stream);
@@ -378,7 +413,9 @@ int rt_dp_create(const rt_dp_config *cfg, rt_dp_ctx **out) {
 void rt_dp_destroy(rt_dp_ctx *ctx) {
     if (!ctx) return;
     DeviceGuard guard(ctx->device);
+    if (ctx->launched_pending) (void)hipEventSynchronize(ctx->launched);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->launched) (void)hipEventDestroy(ctx->launched);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->d_stream) (void)hipFree(ctx->d_stream);
@@ -390,7 +427,7 @@ void rt_dp_destroy(rt_dp_ctx *ctx) {
         if (q) (void)hipFree(q);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    if (g_default_ctx == ctx) g_default_ctx = nullptr;
+    if (g_default_ctx.p == ctx) g_default_ctx.p = nullptr;
     delete ctx;
 }
 
@@ -401,7 +438,25 @@ int rt_dp_launch(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *o
     if (!(in->flags & RT_DP_F_DEVICE_PTRS)) return fail(RT_DP_EINVAL, "rt_dp_launch needs RT_DP_F_DEVICE_PTRS; use rt_dp_eval_ctx for host arrays");
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
-    return launch_device(ctx, in, out, hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream);
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream;
+    const bool beats = ctx->extended && (in->n[RT_DP_OP_EUCLIDEAN] || in->n[RT_DP_OP_ANGULAR]);
+    if (s == ctx->stream) {
+        rc = join_caller_stream(ctx, false);
+        if (rc != RT_DP_OK) return rc;
+    }
+    rc = launch_device(ctx, in, out, s);
+    if (rc != RT_DP_OK) return rc;
+    if (s != ctx->stream && beats) {
+        // the registers were read and written on the caller's stream: remember where, unless the stream is being
+        // captured into a graph (an event recorded there cannot be waited for from outside the graph)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        if (cap == hipStreamCaptureStatusNone) {
+            HIP_TRY(hipEventRecord(ctx->launched, s));
+            ctx->launched_pending = true;
+        }
+    }
+    return RT_DP_OK;
 }
 
 int rt_dp_synchronize(rt_dp_ctx *ctx) {
@@ -421,20 +476,23 @@ int rt_dp_eval_ctx(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch 
         // The operands may still be in production on some other stream of the caller; the
         // synchronous entry point waits for the whole device before it reads them.
         HIP_TRY(hipDeviceSynchronize());
+        ctx->launched_pending = false;  // whatever ran on a caller stream has finished
         rc = launch_device(ctx, in, out, ctx->stream);
         if (rc != RT_DP_OK) return rc;
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         return RT_DP_OK;
     }
+    rc = join_caller_stream(ctx, false);
+    if (rc != RT_DP_OK) return rc;
     return eval_host(ctx, in, out);
 }
 
 int rt_dp_eval(const rt_dp_op_batch *in, rt_dp_result_batch *out) {
-    if (!g_default_ctx) {
-        int rc = rt_dp_create(nullptr, &g_default_ctx);
+    if (!g_default_ctx.p) {
+        int rc = rt_dp_create(nullptr, &g_default_ctx.p);
         if (rc != RT_DP_OK) return rc;
     }
-    return rt_dp_eval_ctx(g_default_ctx, in, out);
+    return rt_dp_eval_ctx(g_default_ctx.p, in, out);
 }
 
 int rt_dp_reset(rt_dp_ctx *ctx) {
@@ -445,6 +503,8 @@ int rt_dp_reset(rt_dp_ctx *ctx) {
 int rt_dp_get_accum(rt_dp_ctx *ctx, float acc[3]) {
     if (!ctx || !acc) return fail(RT_DP_ENULL, "rt_dp_get_accum: NULL argument");
     DeviceGuard guard(ctx->device);
+    int rc = join_caller_stream(ctx, true);
+    if (rc != RT_DP_OK) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(acc, ctx->d_state + 4 * ctx->cur, 3 * sizeof(float), hipMemcpyDeviceToHost));
     return RT_DP_OK;
@@ -453,6 +513,8 @@ int rt_dp_get_accum(rt_dp_ctx *ctx, float acc[3]) {
 int rt_dp_set_accum(rt_dp_ctx *ctx, const float acc[3]) {
     if (!ctx || !acc) return fail(RT_DP_ENULL, "rt_dp_set_accum: NULL argument");
     DeviceGuard guard(ctx->device);
+    int rc = join_caller_stream(ctx, true);
+    if (rc != RT_DP_OK) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const float v[4] = {acc[0], acc[1], acc[2], 0.0f};
     HIP_TRY(hipMemcpy(ctx->d_state + 4 * ctx->cur, v, sizeof v, hipMemcpyHostToDevice));
@@ -1121,6 +1183,23 @@ int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value) {
     } else {
         return fail(RT_DP_EINVAL, "unknown option '%s'", key);
     }
+    return RT_DP_OK;
+}
+
+int rt_dp_get_option(rt_dp_ctx *ctx, const char *key, int *value) {
+    if (!ctx || !key || !value) return fail(RT_DP_ENULL, "rt_dp_get_option: NULL argument");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
+    if (!strcmp(key, "variant")) *value = ctx->tuning.variant;
+    else if (!strcmp(key, "wgs_per_cu")) *value = ctx->tuning.wgs_per_cu;
+    else if (!strcmp(key, "stream_mode")) *value = ctx->stream_mode;
+    else if (!strcmp(key, "vec_passes")) *value = ctx->tuning.vec_passes ? ctx->tuning.vec_passes : 0;
+    else if (!strcmp(key, "ops_per_lane")) *value = ctx->tuning.ops_per_lane ? ctx->tuning.ops_per_lane : 1;
+    else if (!strcmp(key, "nontemporal")) *value = ctx->tuning.nontemporal == 2 ? 0 : 1;
+    else if (!strcmp(key, "vec_tile")) *value = ctx->tuning.vec_tile > 0 ? (ctx->tuning.vec_tile < 64 ? 64 : ctx->tuning.vec_tile) : 512;
+    else if (!strcmp(key, "box_wgs_per_cu")) *value = resolved_residency(ctx->tuning, true);
+    else if (!strcmp(key, "tri_wgs_per_cu")) *value = resolved_residency(ctx->tuning, false);
+    else return fail(RT_DP_EINVAL, "unknown option '%s'", key);
     return RT_DP_OK;
 }
 

@@ -220,7 +220,7 @@ size_t bvh_device_workspace(uint32_t n_tris) {
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_temp, nul, nul, nul, nul, (int)n_tris, 0, 30);
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_temp, nul, nul, (int)n_tris);
     const size_t temp = sort_temp > scan_temp ? sort_temp : scan_temp;
-    return ((size_t)n_tris * (16 + 16 + 12 + 8) + 512 + temp + 255) & ~size_t(255);
+    return ((size_t)n_tris * (16 + 16 + 12 + 8) + 512 + 256 + temp + 255) & ~size_t(255);  // 256: the sort / scan scratch starts on a 256-byte boundary
 }
 
 // Returns the number of nodes through *n_nodes (a host variable; at most n).  Synchronises the stream once per level.
@@ -232,7 +232,9 @@ hipError_t bvh_build_device(const float *tris, uint32_t n, uint32_t leaf_size, c
     uint2 *ranges[2] = {reinterpret_cast<uint2 *>(vals2 + n), reinterpret_cast<uint2 *>(vals2 + n) + n};
     uint32_t *cuts = reinterpret_cast<uint32_t *>(ranges[1] + n);
     uint32_t *inner = cuts + 3 * (size_t)n, *offsets = inner + n;
-    char *temp = reinterpret_cast<char *>(offsets + n);
+    // the library scratch of the radix sort / scan holds 8- and 16-byte records: start it on a 256-byte boundary
+    // whatever the parity of n (the workspace itself comes from hipMalloc and is 256-byte aligned)
+    char *temp = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(offsets + n) + 255u) & ~uintptr_t(255));
     const size_t temp_bytes = workspace_bytes - (size_t)(temp - workspace);
     const unsigned blocks = (n + 255) / 256;
     static const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};

@@ -55,6 +55,7 @@ struct Tuning {
 hipError_t launch_box(const BoxArgs &args, uint64_t n, const Tuning &t, hipStream_t stream, bool derive = false);  // derive: in[6..8] unused
 hipError_t launch_tri(const TriArgs &args, uint64_t n, const Tuning &t, hipStream_t stream, bool derive = false);  // derive: in[3..5] = dir, k unused
 hipError_t launch_euclid(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
+int resolved_residency(const Tuning &t, bool box);  // workgroups per CU that large box / triangle batches run with (0: no cap), per the occupancy query
 hipError_t launch_angular(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
 
 // Stream front-end (stream.hip): device-side stable partition of record streams by opcode.

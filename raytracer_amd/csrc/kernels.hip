@@ -19,6 +19,9 @@
 // src/main/scala/raytracer_datapath/UnifiedDatapath.scala unless stated.
 #include "ops.hpp"
 
+#include <cstdlib>
+#include <mutex>
+
 #pragma clang fp contract(off)
 
 namespace rtdp {
@@ -480,15 +483,65 @@ static inline int min_align(const void *const *ptrs, int count) {
 // of LDS as dynamic shared memory, which the kernel never touches.
 constexpr int kBoxWgsPerCu = 3, kTriWgsPerCu = 5, kVecWgsPerCu = 99;  // from sweeps on MI355X
 
-static unsigned residency_lds(int wgs, int dflt, unsigned static_lds) {
-    int w = (wgs > 0) ? wgs : dflt;
-    if (w >= 99 || w <= 0) return 0u;
-    if (w < 3) w = 3;  // more than 64 KiB of dynamic LDS per workgroup would need a function attribute
-    if (w > 16) return 0u;
+static unsigned residency_lds_guess(int w, unsigned static_lds) {
     // gfx950 hands out LDS in granules of 1280 bytes, 128 of them per CU (measured: the plateaus of the
     // kernel time against the requested size end at 20480, 23040, 26880, 32000, 40960 and 53760 bytes)
     const unsigned share = (128u / (unsigned)w) * 1280u;  // w shares fit, w + 1 do not
     return share > static_lds ? share - static_lds : 0u;
+}
+
+// The granule above is a measurement, not an architectural promise, so the size is verified with the runtime's
+// occupancy query once per (kernel, residency): if the guess does not yield exactly `w` resident workgroups, sizes
+// between the share of w + 1 and the share of w workgroups are tried until one does; failing that, the measured size
+// stays in use.  `achieved` is the query's answer for the size in use, so a caller can see a cap that did not take.
+struct Residency { unsigned lds; int achieved; };
+
+static Residency resolve_residency(const void *kernel, int w, unsigned static_lds) {
+    auto occupancy = [&](unsigned lds) -> int {
+        int blocks = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, 256, lds) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        return blocks;
+    };
+    const unsigned guess = residency_lds_guess(w, static_lds);
+    int got = occupancy(guess);
+    if (got == w || got < 0) return {guess, got < 0 ? w : got};  // query unavailable: keep the measured size
+    const unsigned total = 160u * 1024u;
+    unsigned lo = total / (unsigned)(w + 1), hi = total / (unsigned)w;
+    if (hi > 65536u) hi = 65536u;  // more dynamic LDS per workgroup would need a function attribute
+    for (unsigned size = hi; size + 1 > lo && size >= 256u; size -= 256u) {
+        const unsigned lds = size > static_lds ? size - static_lds : 0u;
+        if (occupancy(lds) == w) return {lds, w};
+    }
+    return {guess, got};  // nothing in the window the hardware's 160 KiB allow: keep the measured size, report the query's answer
+}
+
+static Residency residency(const void *kernel, int slot, int wgs, int dflt, unsigned static_lds) {
+    int w = (wgs > 0) ? wgs : dflt;
+    if (w >= 99 || w <= 0 || w > 16) return {0u, 0};  // no cap
+    if (w < 3) w = 3;
+    // one entry per (kernel slot, residency); filled on first use, read-mostly afterwards
+    static std::mutex lock;
+    static Residency cache[8][17];
+    static bool known[8][17];
+    std::lock_guard<std::mutex> hold(lock);
+    if (!known[slot][w]) {
+        cache[slot][w] = resolve_residency(kernel, w, static_lds);
+        known[slot][w] = true;
+    }
+    return cache[slot][w];
+}
+
+enum { kSlotBox = 0, kSlotBoxDerive, kSlotTri, kSlotTriDerive, kSlotEuc, kSlotAng };
+
+static unsigned residency_lds(const void *kernel, int slot, int wgs, int dflt, unsigned static_lds) {
+    return residency(kernel, slot, wgs, dflt, static_lds).lds;
+}
+
+// What the box / triangle launches of a large batch get with these settings: resident 256-thread workgroups per CU
+// (0 = no cap) as the occupancy query reports it for the dynamic-LDS size in use.
+int resolved_residency(const Tuning &t, bool box) {
+    if (box) return residency(reinterpret_cast<const void *>(&k_box<1, true>), kSlotBox, t.wgs_per_cu, kBoxWgsPerCu, 0u).achieved;
+    return residency(reinterpret_cast<const void *>(&k_tri<1, true>), kSlotTri, t.wgs_per_cu, kTriWgsPerCu, 0u).achieved;
 }
 
 #define RTDP_LAUNCH_OPS(KERNEL, ARGS, FIRST, N, V, NT, STREAM, LDS)                                             \
@@ -550,7 +603,8 @@ hipError_t launch_box(const BoxArgs &args, uint64_t n, const Tuning &t, hipStrea
     for (int i = 0; i < 4; ++i) ptrs[kBoxFields + i] = args.tmin[i];
     ptrs[kBoxFields + 4] = args.flags;
     const int v = pick_v(t.ops_per_lane, min_align(ptrs, kBoxFields + 5), 1);  // measured with the residency cap: 1 beats 2 and 4 from 2^20 to 2^25 ops
-    const unsigned lds = residency_lds(t.wgs_per_cu, n >= (uint64_t(1) << 20) ? kBoxWgsPerCu : 99, 0u);
+    const unsigned lds = derive ? residency_lds(reinterpret_cast<const void *>(&k_box_derive<1, true>), kSlotBoxDerive, t.wgs_per_cu, n >= (uint64_t(1) << 20) ? kBoxWgsPerCu : 99, 0u)
+                                : residency_lds(reinterpret_cast<const void *>(&k_box<1, true>), kSlotBox, t.wgs_per_cu, n >= (uint64_t(1) << 20) ? kBoxWgsPerCu : 99, 0u);
     if (derive) {
         if (use_nt(t)) launch_box_derive_v<true>(args, 0, n, v, lds, stream);
         else launch_box_derive_v<false>(args, 0, n, v, lds, stream);
@@ -568,7 +622,8 @@ hipError_t launch_tri(const TriArgs &args, uint64_t n, const Tuning &t, hipStrea
     ptrs[kTriFields + 2] = args.t_denom;
     ptrs[kTriFields + 3] = args.hit;
     const int v = pick_v(t.ops_per_lane, min_align(ptrs, kTriFields + 4), 1);  // measured: never slower than 2, 5-20 % faster below 2^24 ops
-    const unsigned lds = residency_lds(t.wgs_per_cu, n >= (uint64_t(1) << 21) ? kTriWgsPerCu : 99, 0u);
+    const unsigned lds = derive ? residency_lds(reinterpret_cast<const void *>(&k_tri_derive<1, true>), kSlotTriDerive, t.wgs_per_cu, n >= (uint64_t(1) << 21) ? kTriWgsPerCu : 99, 0u)
+                                : residency_lds(reinterpret_cast<const void *>(&k_tri<1, true>), kSlotTri, t.wgs_per_cu, n >= (uint64_t(1) << 21) ? kTriWgsPerCu : 99, 0u);
     if (derive) {
         if (use_nt(t)) launch_tri_derive_v<true>(args, 0, n, v, lds, stream);
         else launch_tri_derive_v<false>(args, 0, n, v, lds, stream);
@@ -600,7 +655,8 @@ template <bool EUC> static hipError_t launch_vec(const VecArgs &args, uint64_t n
     if (tile < 64u) tile = 64u;
     const uint64_t blocks = (n + tile - 1) / tile;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const unsigned lds = residency_lds(t.wgs_per_cu, kVecWgsPerCu, 8192u);  // the kernel's own LDS stays below 8 KiB
+    const unsigned lds = residency_lds(reinterpret_cast<const void *>(&k_vec<EUC, true, EUC ? 8 : 4, 4>), EUC ? kSlotEuc : kSlotAng, t.wgs_per_cu, kVecWgsPerCu,
+                                       8192u + 64u);  // the kernel's own LDS stays below 8 KiB
     const int walk = (t.variant == 21) ? 1 : 4;  // variant 21 (A/B only): one LDS round trip per beat of the serial walk
     if (use_nt(t)) launch_vec_p<EUC, true>(args, n, tile, passes, walk, (unsigned)blocks, lds, stream);
     else launch_vec_p<EUC, false>(args, n, tile, passes, walk, (unsigned)blocks, lds, stream);

@@ -31,6 +31,13 @@ def torch_cuda():
 
 @pytest.fixture()
 def ctx():
+    # torch first: it brings its own libamdhip64, and the HIP runtime that is loaded first serves the whole
+    # process; with the system one loaded first (through librt_dp.so) torch does not see the GPU
+    try:
+        import torch
+        torch.cuda.is_available()
+    except ImportError:
+        pass
     from raytracer_amd import capi
     c = capi.Context()
     yield c

@@ -1,0 +1,123 @@
+"""Library behaviours around the op kernels: the residency cap as the runtime's occupancy query sees it, the
+accumulator calls against batches launched on a caller's stream, argument errors reported before anything runs,
+and the per-thread default context of rt_dp_eval."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import gen
+from raytracer_amd import capi
+
+from helpers import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+f32, u32 = np.float32, np.uint32
+
+
+def test_resolved_residency_is_the_default_table(torch_cuda, ctx):
+    """Box batches run with 3 resident workgroups per CU, triangle batches with 5 (the measured optima); the cap is
+    requested through dynamic LDS, and the occupancy query of the runtime must agree that it took."""
+    assert ctx.get_option("box_wgs_per_cu") == 3
+    assert ctx.get_option("tri_wgs_per_cu") == 5
+    for w in (3, 4, 6, 8):
+        ctx.set_option("wgs_per_cu", w)
+        assert ctx.get_option("wgs_per_cu") == w
+        assert ctx.get_option("box_wgs_per_cu") == w, "cap %d did not take" % w
+    ctx.set_option("wgs_per_cu", 99)
+    assert ctx.get_option("box_wgs_per_cu") == 0 and ctx.get_option("tri_wgs_per_cu") == 0
+    ctx.set_option("wgs_per_cu", 0)
+    assert ctx.get_option("ops_per_lane") == 1 and ctx.get_option("nontemporal") == 1 and ctx.get_option("vec_tile") == 512
+    with pytest.raises(capi.RtDpError):
+        ctx.get_option("no_such_knob")
+
+
+def test_accumulator_calls_wait_for_a_callers_stream(ctx, oracle, torch_cuda):
+    """rt_dp_launch on a caller stream, then rt_dp_get_accum / rt_dp_set_accum / a batch on the context's own stream
+    with no synchronisation in between: each sees the registers the launched batch left."""
+    torch = torch_cuda
+    a, b, ctl, _ = gen.vec_beats(60000, 16, seed=71)
+    ctl = ctl.copy()
+    ctl[-1] &= u32(0xFFFF)                       # ends inside a pair: the register is live afterwards
+    want, acc = oracle.euclid_beats(a, b, ctl, 0.0)
+    da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    dc = torch.from_numpy(ctl.view(np.int32)).cuda()
+    out = torch.empty(ctl.shape[0], dtype=torch.float32, device="cuda")
+    bt = capi.Batch()
+    bt.set_euclid(da, db, dc, out)
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        ctx.reset()
+        # something slow in front of the batch on the caller's stream, so that an unordered read would come too early
+        with torch.cuda.stream(stream):
+            x = torch.ones(1 << 26, device="cuda")
+            for _i in range(10):
+                x = x * 1.0001
+        ctx.launch(bt, stream.cuda_stream)
+        got = ctx.get_accum()                    # no synchronisation by the caller
+        assert_bits_equal(got[0:1], np.array([acc], f32), "register read right behind a launch on a caller stream")
+    # a second batch through the synchronous entry point continues from the launched one
+    ctx.reset()
+    ctx.launch(bt, stream.cuda_stream)
+    tail_a, tail_b, tail_ctl, _ = gen.vec_beats(10, 16, seed=72)
+    want2, _ = oracle.euclid_beats(tail_a, tail_b, tail_ctl, acc)
+    out2 = np.zeros(tail_ctl.shape[0], f32)
+    b2 = capi.Batch()
+    b2.set_euclid(tail_a, tail_b, tail_ctl, out2)
+    ctx.eval(b2)                                 # host arrays, the context's own stream
+    assert_bits_equal(out2, want2, "batch on the context stream behind a batch on a caller stream")
+    assert_bits_equal(out.cpu().numpy(), want, "the launched batch itself")
+
+
+def test_misaligned_beat_arrays_are_refused_before_anything_runs(ctx, torch_cuda):
+    torch = torch_cuda
+    n = 1000
+    fields = [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in gen.box_ops(n, seed=5)]
+    tmin = [torch.full((n,), -7.0, dtype=torch.float32, device="cuda") for _ in range(4)]
+    flags = torch.full((n,), 0x5A5A, dtype=torch.int32, device="cuda")
+    pool = torch.zeros(16 * 64 + 16, dtype=torch.float32, device="cuda")
+    b = capi.Batch()
+    b.set_box(fields, tmin, flags)
+    b.set_euclid(pool[1:1 + 16 * 64].view(64, 16), pool[0:16 * 64].view(64, 16), torch.zeros(64, dtype=torch.int32, device="cuda"),
+                 torch.zeros(64, dtype=torch.float32, device="cuda"))     # euc.a is 4 bytes off a 16-byte boundary
+    torch.cuda.synchronize()
+    with pytest.raises(capi.RtDpError) as e:
+        ctx.launch(b)
+    assert e.value.code == capi.EALIGN
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    assert bool((flags == 0x5A5A).all()) and bool((tmin[0] == -7.0).all()), "the box segment ran although the batch was refused"
+
+
+def test_default_context_of_a_thread_is_released_when_the_thread_ends(torch_cuda):
+    """rt_dp_eval keeps a per-thread context (8 MiB of device staging once host arrays went through it); threads that
+    come and go must not pile these up."""
+    torch = torch_cuda
+    L = capi.load()
+    fields = gen.box_ops(500, seed=9)
+
+    def one_call():
+        torch.cuda.set_device(0)
+        n = 500
+        tmin = [np.zeros(n, f32) for _ in range(4)]
+        flags = np.zeros(n, u32)
+        b = capi.Batch()
+        b.set_box([np.ascontiguousarray(f, f32) for f in fields], tmin, flags)
+        b.finalize()
+        assert L.rt_dp_eval(C.byref(b.ob), C.byref(b.rb)) == 0
+
+    def run_threads(k):
+        for _ in range(k):
+            t = threading.Thread(target=one_call)
+            t.start()
+            t.join()
+
+    run_threads(2)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    run_threads(24)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, "24 short-lived threads cost %d MiB of device memory" % ((free0 - free1) >> 20)
