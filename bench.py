@@ -7,15 +7,20 @@ A step is one pass of the hot path over one resident batch of synthetic
 operands.  Headline workload (N = 1): 2^24 random ray-vs-4-AABB box ops, SoA
 fp32 operands already in HBM.  With N > 1 every rank runs the same-size batch on
 its own GPU (independent op streams, no collective on the data path: weak
-scaling) and rank 0 prints the whole-job rate.
+scaling) and rank 0 prints the whole-job rate.  `--gpus N` from a plain shell
+starts the N ranks itself; under torchrun the ranks are taken as given.
 
 One JSON line is printed by rank 0.  Besides the contract fields it carries
   roofline      -- the dominant kernel against the HBM roof (algorithmic bytes)
   cpu_baseline  -- the scalar C golden model (oracle B) timed on the host cores
-  per_opcode    -- the other three opcodes and a mixed batch, each with a roofline
+  per_opcode    -- the other three opcodes and a mixed batch (2^24 units per GPU, weak), the box and triangle
+                   streams with >= 1 % of every edge class, the 2^28-unit mixed stream cut into one pair-aligned
+                   shard per GPU (strong scaling) and the k-NN configuration (strong scaling, one all-gather),
+                   each with its own roofline / VALU block
 
 Other workloads, one JSON line each:
   --only tri|euclid|angular|mixed     one opcode (or the mixed batch) as the headline
+  --only mixed --strong               the 2^--strong-log2-ops mixed stream sharded over the GPUs as the headline
   --only stream [--stream-mode 1|2]   record-at-a-time streams resident in HBM
   --only knn [--knn-tree 0|1|2] [--knn-metric angular] [--knn-data clustered]
                                       exact top-16 search, 2^20 points x 2^16 queries (strong scaling over GPUs)
@@ -86,7 +91,7 @@ def parse():
     p.add_argument("--variant", type=int, default=0)
     p.add_argument("--vec-passes", type=int, default=0)
     p.add_argument("--wgs-per-cu", type=int, default=0, help="resident workgroups per CU of the op kernels: 0 library default, 3..16, 99 no cap")
-    p.add_argument("--only", default="", help="restrict to one workload: box|tri|euclid|angular|mixed")
+    p.add_argument("--only", default="", help="restrict to one workload: box|tri|euclid|angular|mixed|box_edge|tri_edge|stream|knn|trace")
     # tuning: 0 = library default; nontemporal 1 = on, 2 = off
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -108,16 +113,22 @@ def parse():
     p.add_argument("--derive", type=int, default=0, help="1: box / tri workloads derive inv / shear / k from dir inside the kernels "
                    "(RT_DP_F_DERIVE_RAY: 144 and 72 algorithmic bytes per op); not the headline format")
     p.add_argument("--sweep", action="store_true", help="A/B the kernel shapes instead of the timed run")
+    p.add_argument("--strong", action="store_true", help="with --only mixed: one 2^--strong-log2-ops stream cut into one shard per GPU (strong scaling)")
+    p.add_argument("--strong-log2-ops", type=int, default=28, help="units of the sharded mixed stream (whole job)")
+    p.add_argument("--edge-per-class", type=float, default=0.01, help="fraction of the ops of the edge streams in each edge class")
+    p.add_argument("--no-extras", action="store_true", help="default line without the edge streams, the sharded 2^28 stream and k-NN")
+    p.add_argument("--verify", action="store_true", help="sharded mixed stream: also evaluate the whole stream on rank 0 and compare it with the "
+                                                         "shards' results put together (small sizes only: results travel through host memory)")
     return p.parse_args()
 
 
-def make_batches(n, dev, which, stagger_kib=0, derive=False, launch_ops=0):
+def make_batches(n, dev, which, stagger_kib=0, derive=False, launch_ops=0, edge=0.0):
     """Resident operand / result arrays and one capi.Batch per workload."""
     out = {}
     i32, f32 = torch.int32, torch.float32
 
     def box(n_):
-        fields = synth.box_stream(n_, 20241008, dev)
+        fields = synth.box_stream(n_, 20241008, dev, edge)
         tm = torch.empty(4, n_, dtype=f32, device=dev)
         tmin = [tm[0], tm[1], tm[2], tm[3]]
         flags = torch.empty(n_, dtype=i32, device=dev)
@@ -134,7 +145,7 @@ def make_batches(n, dev, which, stagger_kib=0, derive=False, launch_ops=0):
         return fields, tmin, flags
 
     def tri(n_):
-        fields, k = synth.tri_stream(n_, 20241009, dev)
+        fields, k = synth.tri_stream(n_, 20241009, dev, edge)
         return fields, k, torch.empty(n_, dtype=f32, device=dev), torch.empty(n_, dtype=f32, device=dev), torch.empty(n_, dtype=i32, device=dev)
 
     def euc(n_):
@@ -254,36 +265,29 @@ def run(ctx, batch, steps, warmup, dist):
     return wall, dev_ms
 
 
-def roofline(counts, dev_ms):
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
+
+
+def roofline(counts, dev_ms, measured_format=True):
+    """The launch against the HBM roof.  `achieved` is live (algorithmic bytes / HIP-event time of this run); `traffic` and
+    `valu_issue_fraction` are NOT measured in this run: they are the per-unit figures of the committed rocprofv3 --pmc passes
+    (profiles/traffic.json) scaled to this launch, and `traffic_source` says so."""
     algo = sum(BYTES[k] * v for k, v in counts.items())
     gbs = algo / (dev_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": load_traffic(counts), "valu_issue_fraction": load_valu(counts)}
-
-
-def load_valu(counts):
-    """Fraction of the FP32 VALU issue peak from the committed SQ_INSTS_VALU pass (single-opcode batches only)."""
-    try:
-        if BYTES["box"] != 156:
-            return None
-        per_unit = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        (k,) = counts.keys()
-        return per_unit[k].get("valu_issue_fraction")
-    except Exception:
-        return None
-
-
-def load_traffic(counts):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json:
-    {"box": bytes_per_op, ...}, already corrected as the gfx950 counter notes require), or None."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(path) or BYTES["box"] != 156:   # the committed passes measured the plain operand format
-        return None
-    try:
-        per_unit = json.load(open(path))
-        return int(sum(per_unit[k]["hbm_bytes_per_unit"] * v for k, v in counts.items()))
-    except Exception:
-        return None
+    r = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+         "traffic": None, "valu_issue_fraction": None, "traffic_source": None}
+    if measured_format and os.path.exists(TRAFFIC_FILE):   # the committed passes measured the plain operand format
+        try:
+            per_unit = json.load(open(TRAFFIC_FILE))
+            r["traffic"] = int(sum(per_unit[k]["hbm_bytes_per_unit"] * v for k, v in counts.items()))
+            if len(counts) == 1:
+                (k,) = counts.keys()
+                r["valu_issue_fraction"] = per_unit[k].get("valu_issue_fraction")
+            r["traffic_source"] = "profiles/traffic.json (%s), per-unit counter figures x the units of this launch; not re-measured in this run" % per_unit.get(
+                "_source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes")
+        except Exception:
+            pass
+    return r
 
 
 def cpu_baseline(batch, n, seconds):
@@ -418,9 +422,10 @@ def run_trace(a, world, rank, local, dev):
     dist_util.shutdown()
 
 
-def run_knn(a, world, rank, local, dev):
+def knn_measure(a, ctx, world, rank, dev, tree_mode, steps, warmup):
     """k-NN configuration: 2^20 points (sharded over the ranks), 2^16 queries (replicated), dim 16, k = 16;
-    per-GPU partial lists merged after one all-gather.  Total work is fixed: strong scaling."""
+    per-GPU partial lists merged after one all-gather.  Total work is fixed: strong scaling.  Returns the result
+    block (same on every rank)."""
     from raytracer_amd import knn
     n_pts, n_qry = 1 << a.knn_log2_points, 1 << a.knn_log2_queries
     g = torch.Generator(device=dev)
@@ -432,67 +437,189 @@ def run_knn(a, world, rank, local, dev):
         pts = centres[torch.randint(0, 256, (n_pts,), generator=g, device=dev)] + 0.05 * torch.randn(n_pts, 16, generator=g, device=dev)
         qry = centres[torch.randint(0, 256, (n_qry,), generator=g, device=dev)] + 0.05 * torch.randn(n_qry, 16, generator=g, device=dev)
     lo, hi = (rank * n_pts) // world, ((rank + 1) * n_pts) // world
-    shard = pts[lo:hi].contiguous()
-    ctx = capi.Context(device=local)
+    shard_pts = pts[lo:hi].contiguous()
     stream = bench_stream()
     times = []
     tree, build_ms = None, None
-    if a.knn_metric == "angular":
-        a.knn_tree = 0
-    if a.knn_tree:
+    angular = a.knn_metric == "angular"
+    if angular:
+        tree_mode = 0
+    if tree_mode:
         from raytracer_amd import knn_tree
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if a.knn_build == "device":
-            knn_tree.KnnTree.build_device(ctx, shard, leaf_size=a.knn_leaf, index_base=lo)   # first call: workspace allocation
+            knn_tree.KnnTree.build_device(ctx, shard_pts, leaf_size=a.knn_leaf, index_base=lo)   # first call: workspace allocation
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            tree = knn_tree.KnnTree.build_device(ctx, shard, leaf_size=a.knn_leaf, index_base=lo)
+            tree = knn_tree.KnnTree.build_device(ctx, shard_pts, leaf_size=a.knn_leaf, index_base=lo)
         else:
-            tree = knn_tree.KnnTree(shard, leaf_size=a.knn_leaf, index_base=lo)  # index construction: outside the timed queries
+            tree = knn_tree.KnnTree(shard_pts, leaf_size=a.knn_leaf, index_base=lo)  # index construction: outside the timed queries
         torch.cuda.synchronize()
         build_ms = (time.perf_counter() - t0) * 1e3
     with torch.cuda.stream(stream):
-        for it in range(a.warmup + a.steps):
+        for it in range(warmup + steps):
             torch.cuda.synchronize()
             dist_util.barrier()
             t0 = time.perf_counter()
             if tree is not None:
-                d, i = knn_tree.search(ctx, tree, qry, splits=a.knn_splits or None, grouped=(a.knn_tree == 2), walk_leaves=a.knn_walk)
-            elif a.knn_metric == "angular":
-                d, i = knn.unpack_signed_keys(knn.all_gather_merge(knn.local_topk_angular(ctx, shard, qry, lo, splits=a.knn_splits or None)))
+                d, i = knn_tree.search(ctx, tree, qry, splits=a.knn_splits or None, grouped=(tree_mode == 2), walk_leaves=a.knn_walk)
+            elif angular:
+                d, i = knn.unpack_signed_keys(knn.all_gather_merge(knn.local_topk_angular(ctx, shard_pts, qry, lo, splits=a.knn_splits or None)))
             else:
-                d, i = knn.search(ctx, shard, qry, lo, splits=a.knn_splits or None)
+                d, i = knn.search(ctx, shard_pts, qry, lo, splits=a.knn_splits or None)
             torch.cuda.synchronize()
             dist_util.barrier()
-            if it >= a.warmup:
+            if it >= warmup:
                 times.append(time.perf_counter() - t0)
     wall = dist_util.max_over_ranks(sum(times), device="cuda")
+    per = wall / steps
+    pairs = float(n_pts) * n_qry
+    if angular:   # the candidate's norm is computed once per point, not per pair
+        lane_ops, note = 35, "16 mul + 16 add (dot, two beats) + 1 mul, 1 add, 1 compare (filter) per pair, none fusable"
+    else:
+        lane_ops, note = 48, "16 sub + 16 mul + 15 add + 1 compare per pair, none fusable"
+    note += "; peak = 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz"
+    return {"metric": "k-NN queries/s (exact, %s, k=16)" % ("angular op score" if angular else "Euclidean beat distance"),
+            "value": round(n_qry / per, 1), "unit": "queries/s", "ms_per_step": round(per * 1e3, 3), "steps": steps, "warmup": warmup, "scaling": "strong",
+            "workload": "knn: 2^%d points sharded over %d GPU(s), 2^%d queries replicated, dim 16, k 16, %s data, one all-gather merge" % (
+                a.knn_log2_points, world, a.knn_log2_queries, a.knn_data),
+            "search": ("k-d tree %s, leaf %d, index build %.1f ms (not timed)" % ("leaf-major search" if tree_mode == 2 else "walk with box pruning", a.knn_leaf, build_ms)) if tree_mode else "exhaustive",
+            "pair_rate_equivalent_per_s": round(pairs / per, 1),
+            "valu": None if tree_mode else {"lane_ops_per_pair": lane_ops, "achieved_T_lane_ops": round(pairs * lane_ops / per / 1e12, 2), "peak_T_lane_ops": 78.6,
+                                            "frac": round(pairs * lane_ops / per / 78.6e12, 4), "note": note}}
+
+
+def run_knn(a, world, rank, local, dev):
+    ctx = capi.Context(device=local)
+    r = knn_measure(a, ctx, world, rank, dev, a.knn_tree, a.steps, a.warmup)
     if rank == 0:
-        per = wall / a.steps
-        pairs = float(n_pts) * n_qry
-        if a.knn_metric == "angular":   # the candidate's norm is computed once per point, not per pair
-            lane_ops, note = 35, "16 mul + 16 add (dot, two beats) + 1 mul, 1 add, 1 compare (filter) per pair, none fusable"
-        else:
-            lane_ops, note = 48, "16 sub + 16 mul + 15 add + 1 compare per pair, none fusable"
-        note += "; peak = 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz"
-        print(json.dumps({"metric": "k-NN queries/s (exact, %s, k=16)" % ("angular op score" if a.knn_metric == "angular" else "Euclidean beat distance"), "value": round(n_qry / per, 1),
-                          "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-                          "ms_per_step": round(per * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "knn: 2^%d points sharded over %d GPU(s), 2^%d queries replicated, dim 16, k 16, %s data, one all-gather merge" % (
-                              a.knn_log2_points, world, a.knn_log2_queries, a.knn_data)},
-                          "search": ("k-d tree %s, leaf %d, index build %.1f ms (not timed)" % ("leaf-major search" if a.knn_tree == 2 else "walk with box pruning", a.knn_leaf, build_ms)) if a.knn_tree else "exhaustive",
-                          "pair_rate_equivalent_per_s": round(pairs / per, 1),
-                          "valu": None if a.knn_tree else {"lane_ops_per_pair": lane_ops, "achieved_T_lane_ops": round(pairs * lane_ops / per / 1e12, 2), "peak_T_lane_ops": 78.6,
-                                   "frac": round(pairs * lane_ops / per / 78.6e12, 4), "note": note}}), flush=True)
+        print(json.dumps({"metric": r["metric"], "value": r["value"], "unit": r["unit"], "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "config": {"workload": r["workload"]}, "search": r["search"],
+                          "pair_rate_equivalent_per_s": r["pair_rate_equivalent_per_s"], "valu": r["valu"]}), flush=True)
     ctx.close()
     dist_util.shutdown()
+
+
+def make_strong_mixed(total, world, rank, dev, keep_whole=False):
+    """The config-4 stream: `total` units, a quarter per opcode, opcode-sorted; this rank keeps the shard that
+    shard.plan gives it (contiguous ranges, beat segments cut on vector-pair boundaries: every shard starts from +0
+    accumulators and no collective touches the data path).  Every rank draws the same whole stream and keeps its part.
+    Returns (batch of the shard, unit counts of the shard, unit counts of the whole stream, whole-stream arrays or None)."""
+    from raytracer_amd import shard
+    q = total // 4
+    f32, i32 = torch.float32, torch.int32
+    ea, eb, ectl = synth.vec_stream(q, 16, 20241010, dev)
+    aq, ac, actl = synth.vec_stream(q, 8, 20241011, dev)
+    ne, na = int(ectl.shape[0]), int(actl.shape[0])
+    plan = shard.plan(q, q, ectl.cpu().numpy().view(np.uint32), actl.cpu().numpy().view(np.uint32), world)[rank]
+    whole = {} if keep_whole else None
+
+    def cut(t, rng):
+        if world == 1:
+            return t
+        return t[rng[0]:rng[1]].clone()
+
+    if keep_whole:
+        whole.update(ea=ea, eb=eb, ectl=ectl, aq=aq, ac=ac, actl=actl)
+    e = (cut(ea, plan["euclid"]), cut(eb, plan["euclid"]), cut(ectl, plan["euclid"]))
+    g = (cut(aq, plan["angular"]), cut(ac, plan["angular"]), cut(actl, plan["angular"]))
+    del ea, eb, ectl, aq, ac, actl
+    bf = synth.box_stream(q, 20241008, dev)
+    if keep_whole:
+        whole["box"] = bf
+    box = [cut(f, plan["box"]) for f in bf]
+    del bf
+    tf, tk = synth.tri_stream(q, 20241009, dev)
+    if keep_whole:
+        whole["tri"], whole["trik"] = tf, tk
+    tri, trik = [cut(f, plan["tri"]) for f in tf], cut(tk, plan["tri"])
+    del tf, tk
+    torch.cuda.empty_cache()
+    b = batch_from(box, tri, trik, e, g, dev)
+    counts = {"box": int(box[0].shape[0]), "tri": int(tri[0].shape[0]), "euclid": int(e[2].shape[0]), "angular": int(g[2].shape[0])}
+    return b, counts, {"box": q, "tri": q, "euclid": ne, "angular": na}, whole
+
+
+def batch_from(box, tri, trik, euc, ang, dev):
+    """One mixed batch over the given operand arrays with freshly allocated result arrays (kept in batch.results)."""
+    f32, i32 = torch.float32, torch.int32
+    nb, nt, ne, na = int(box[0].shape[0]), int(tri[0].shape[0]), int(euc[2].shape[0]), int(ang[2].shape[0])
+    res = {"tmin": [torch.empty(nb, dtype=f32, device=dev) for _ in range(4)], "flags": torch.empty(nb, dtype=i32, device=dev),
+           "t_num": torch.empty(nt, dtype=f32, device=dev), "t_denom": torch.empty(nt, dtype=f32, device=dev), "hit": torch.empty(nt, dtype=i32, device=dev),
+           "acc": torch.empty(ne, dtype=f32, device=dev), "dot": torch.empty(na, dtype=f32, device=dev), "norm": torch.empty(na, dtype=f32, device=dev)}
+    b = capi.Batch()
+    b.set_box(box, res["tmin"], res["flags"])
+    b.set_tri(tri, trik, res["t_num"], res["t_denom"], res["hit"])
+    b.set_euclid(euc[0], euc[1], euc[2], res["acc"])
+    b.set_angular(ang[0], ang[1], ang[2], res["dot"], res["norm"])
+    b.finalize()
+    b.results = res
+    return b
+
+
+def result_list(res):
+    return res["tmin"] + [res["flags"], res["t_num"], res["t_denom"], res["hit"], res["acc"], res["dot"], res["norm"]]
+
+
+def strong_mixed_measure(a, ctx, world, rank, dev, dist, log2_total, steps, warmup):
+    """Runs the sharded mixed stream; returns the result block (identical on every rank)."""
+    total = 1 << log2_total
+    batch, counts, whole_counts, whole = make_strong_mixed(total, world, rank, dev, keep_whole=a.verify)
+    torch.cuda.synchronize()
+    ctx.reset()
+    wall, dev_ms = run(ctx, batch, steps, warmup, dist)
+    units = sum(whole_counts.values())
+    block = {"value": round(units * steps / wall, 1), "unit": "ops/s", "ms_per_step": round(wall / steps * 1e3, 4), "kernel_ms": round(dev_ms, 4),
+             "steps": steps, "warmup": warmup, "scaling": "strong", "units_whole_job": units, "units_this_gpu": sum(counts.values()),
+             "workload": "mixed: 2^%d-unit opcode-sorted stream (a quarter per opcode), cut by shard.plan into %d pair-aligned shard(s), no collective" % (log2_total, world),
+             "roofline": roofline(counts, dev_ms)}
+    if a.verify:
+        # the shards' results, put together in rank order, must be the whole stream's results (computed on rank 0 in one batch)
+        ctx.reset()
+        ctx.launch(batch, bench_stream().cuda_stream)
+        torch.cuda.synchronize()
+        mine = [t.cpu().numpy().view(np.uint32) for t in result_list(batch.results)]
+        parts = dist_util.gather_objects(mine)
+        ok = None
+        if rank == 0:
+            wb = batch_from(whole["box"], whole["tri"], whole["trik"], (whole["ea"], whole["eb"], whole["ectl"]),
+                            (whole["aq"], whole["ac"], whole["actl"]), dev)
+            c2 = capi.Context(device=torch.cuda.current_device())
+            c2.launch(wb, bench_stream().cuda_stream)
+            torch.cuda.synchronize()
+            c2.close()
+            want = [t.cpu().numpy().view(np.uint32) for t in result_list(wb.results)]
+            ok = all(np.array_equal(np.concatenate([p[k] for p in parts]), want[k]) for k in range(len(want)))
+        block["verified_against_whole_stream"] = ok
+    del batch
+    torch.cuda.empty_cache()
+    return block
+
+
+def resolved_tuning(ctx, a):
+    """The kernel shapes actually in effect (library defaults filled in), for the JSON line."""
+    t = {"requested": {"ops_per_lane": a.ops_per_lane, "nontemporal": a.nontemporal, "vec_tile": a.vec_tile, "variant": a.variant,
+                       "vec_passes": a.vec_passes, "derive": a.derive, "wgs_per_cu": a.wgs_per_cu}}
+    for key in ("ops_per_lane", "nontemporal", "vec_tile", "vec_passes", "box_wgs_per_cu", "tri_wgs_per_cu"):
+        try:
+            t[key] = ctx.get_option(key)
+        except capi.RtDpError:
+            t[key] = None
+    if t.get("vec_passes") == 0:
+        t["vec_passes"] = {"euclid": 8, "angular": 4}
+    if not a.vec_tile:
+        t["vec_tile"] = {"euclid": 512, "angular": 504}
+    t["beat_kernel_wgs_per_cu"] = "uncapped"
+    return t
 
 
 def main():
     a = parse()
     world, rank, local = dist_util.env_world()
+    if a.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but the launch environment has %d rank(s); reporting n_gpus = %d" % (a.gpus, world, world), file=sys.stderr)
     if os.environ.get("RT_DP_REHEARSE_ONE_GPU") == "1":
         # rehearsal of the N > 1 control path on a one-GPU box: every rank uses GPU 0 and the
         # control collectives go over gloo (RCCL refuses two ranks on one device); timings are meaningless
@@ -516,13 +643,32 @@ def main():
         run_trace(a, world, rank, local, dev)
         return
 
-    which = [a.only] if a.only else ["box", "tri", "euclid", "angular", "mixed"]
     ctx = capi.Context(device=local)
     ctx.set_tuning(a.ops_per_lane, a.nontemporal, a.vec_tile, a.variant, a.vec_passes)
     ctx.set_option("wgs_per_cu", a.wgs_per_cu)
+    tuning = resolved_tuning(ctx, a)
+
+    if a.only == "mixed" and a.strong:
+        r = strong_mixed_measure(a, ctx, world, rank, dev, dist, a.strong_log2_ops, a.steps, a.warmup)
+        if rank == 0:
+            print(json.dumps({"metric": "datapath ops/s (mixed opcodes, one stream sharded over the GPUs)", "value": r["value"], "unit": "ops/s",
+                              "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
+                              "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": r["workload"], "units_whole_job": r["units_whole_job"], "units_this_gpu": r["units_this_gpu"],
+                                         "sharding": "shard.plan: contiguous ranges per opcode segment, beat segments cut on vector-pair boundaries", "tuning": tuning},
+                              "roofline": r["roofline"], "cpu_baseline": None,
+                              "verified_against_whole_stream": r.get("verified_against_whole_stream")}), flush=True)
+        ctx.close()
+        dist_util.shutdown()
+        return
+
+    which = [a.only] if a.only else ["box", "tri", "euclid", "angular", "mixed"]
+    only_edge = 0.0
+    if a.only in ("box_edge", "tri_edge"):      # the edge-class stream of one opcode as the headline
+        which, only_edge = [a.only.split("_")[0]], a.edge_per_class
     if a.derive:
         BYTES.update(box=144, tri=72)
-    batches = make_batches(n, dev, which, a.stagger_kib, bool(a.derive), a.launch_ops)
+    batches = make_batches(n, dev, which, a.stagger_kib, bool(a.derive), a.launch_ops, only_edge)
     torch.cuda.synchronize()
 
     if a.sweep:
@@ -531,13 +677,39 @@ def main():
         ctx.close()
         return
 
+    plain = not a.derive      # the committed counter passes measured the plain operand format
     results = {}
     for name in which:
         batch, counts = batches[name]
         wall, dev_ms = run(ctx, batch, a.steps, a.warmup, dist)
         units = sum(counts.values())
-        results[name] = {"value": units * world * a.steps / wall, "ms_per_step": wall / a.steps * 1e3,
-                         "kernel_ms": dev_ms, "units_per_gpu": units, "roofline": roofline(counts, dev_ms)}
+        results[name] = {"value": units * world * a.steps / wall, "ms_per_step": wall / a.steps * 1e3, "scaling": "weak",
+                         "kernel_ms": dev_ms, "units_per_gpu": units, "roofline": roofline(counts, dev_ms, plain)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and "box" in batches:
+        cpu = cpu_baseline(batches["box"][0], n, a.cpu_seconds)
+    extras = {}
+    if not a.only and not a.no_extras:
+        del batches
+        torch.cuda.empty_cache()
+        # config 2 / 3 with their edge classes: >= 1 % of the ops in every class, same size as the headline
+        eb = make_batches(n, dev, ["box", "tri"], 0, False, 0, edge=a.edge_per_class)
+        for name in ("box", "tri"):
+            batch, counts = eb[name]
+            wall, dev_ms = run(ctx, batch, a.steps, a.warmup, dist)
+            results[name + "_edge"] = {"value": counts[name] * world * a.steps / wall, "ms_per_step": wall / a.steps * 1e3, "scaling": "weak",
+                                       "kernel_ms": dev_ms, "units_per_gpu": counts[name], "roofline": roofline(counts, dev_ms, plain),
+                                       "edge_classes": {"per_class": a.edge_per_class,
+                                                        "classes": synth.BOX_EDGE_CLASSES if name == "box" else synth.TRI_EDGE_CLASSES}}
+        del eb
+        torch.cuda.empty_cache()
+        # config 4: the 2^28-unit mixed stream, one shard per GPU
+        extras["mixed_2p%d" % a.strong_log2_ops] = strong_mixed_measure(a, ctx, world, rank, dev, dist, a.strong_log2_ops, a.steps, a.warmup)
+        # config 5: k-NN, exhaustive and leaf-major
+        ksteps, kwarm = max(1, min(a.steps, 5)), max(1, min(a.warmup, 2))
+        extras["knn"] = {"exhaustive": knn_measure(a, ctx, world, rank, dev, 0, ksteps, kwarm),
+                         "leaf_major": knn_measure(a, ctx, world, rank, dev, 2, ksteps, kwarm)}
 
     head = which[0]
     r = results[head]
@@ -550,17 +722,16 @@ def main():
         "config": {"workload": "%s: %s random ray-vs-4-AABB box ops per GPU, SoA fp32 operands resident in HBM" % (head, size_text)
                    if head == "box" else "%s, %s units per GPU" % (head, size_text),
                    "ops_per_gpu": r["units_per_gpu"], "bytes_per_op": BYTES.get(head), "sharding": "independent op streams per GPU, no collective",
-                   "tuning": {"ops_per_lane": a.ops_per_lane, "nontemporal": a.nontemporal, "vec_tile": a.vec_tile, "variant": a.variant, "vec_passes": a.vec_passes, "derive": a.derive, "wgs_per_cu": a.wgs_per_cu}},
+                   "tuning": tuning},
         "roofline": r["roofline"],
     }
     if rank == 0:
-        if world == 1 and not a.no_cpu_baseline and "box" in batches:
-            line["cpu_baseline"] = cpu_baseline(batches["box"][0], n, a.cpu_seconds)
-        else:
-            line["cpu_baseline"] = None
-        line["per_opcode"] = {k: {"value": round(v["value"], 1), "unit": "ops/s" if k in ("box", "tri", "mixed") else "beats/s",
-                                  "kernel_ms": round(v["kernel_ms"], 4), "units_per_gpu": v["units_per_gpu"], "roofline": v["roofline"]}
+        line["cpu_baseline"] = cpu
+        line["per_opcode"] = {k: {"value": round(v["value"], 1), "unit": "ops/s" if k.split("_")[0] in ("box", "tri", "mixed") else "beats/s",
+                                  "scaling": v["scaling"], "kernel_ms": round(v["kernel_ms"], 4), "units_per_gpu": v["units_per_gpu"],
+                                  "roofline": v["roofline"], **({"edge_classes": v["edge_classes"]} if "edge_classes" in v else {})}
                               for k, v in results.items()}
+        line["per_opcode"].update(extras)
         print(json.dumps(line), flush=True)
     ctx.close()
     dist_util.shutdown()

@@ -519,8 +519,9 @@ int rt_dp_bvh4_build_device(rt_dp_ctx *ctx, const float *tris, uint32_t n_tris, 
 int rt_dp_set_tuning(rt_dp_ctx *ctx, int ops_per_lane, int nontemporal, int vec_tile);
 /* Further integer knobs by name: "vec_passes" (opcodes 2/3: 16-byte load pairs in flight per
  * lane and sub-tile, 2 / 4 / 8), "variant" (0 normal; 10 diagnostic: the box kernel's memory
- * pattern without its arithmetic, outputs meaningless; 21 A/B: the beat kernels fetch one beat sum per LDS round
- * trip of the serial accumulation instead of four, results identical).  Environment: RT_DP_VEC_PASSES,
+ * pattern without its arithmetic, outputs meaningless; 21 / 22 A/B: the beat kernels' serial accumulation
+ * with one beat sum per LDS round trip everywhere / with four everywhere; by default a workgroup that owns a
+ * vector pair longer than four tiles takes the second form, all others the first; results identical).  Environment: RT_DP_VEC_PASSES,
  * RT_DP_VARIANT.  "wgs_per_cu" (resident 256-thread workgroups per CU of the box / triangle / beat
  * kernels: 0 the measured per-kernel default, 3..16, 99 as many as fit; environment RT_DP_WGS_PER_CU).
  * "stream_mode" selects how rt_dp_eval_bundles_device works: 1 partitions the
@@ -528,7 +529,7 @@ int rt_dp_set_tuning(rt_dp_ctx *ctx, int ops_per_lane, int nontemporal, int vec_
  * pass (needs 16-byte aligned record arrays), 0 (default) picks 2 when the alignment allows. */
 int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value);
 /* Reads a knob back as the library resolved it: the keys above give the value in effect ("ops_per_lane",
- * "nontemporal" 0/1, "vec_tile" with the defaults filled in), and "box_wgs_per_cu" / "tri_wgs_per_cu" give the
+ * "nontemporal" 0/1, "vec_tile" with the Euclidean default filled in: the angular default is 8 beats shorter), and "box_wgs_per_cu" / "tri_wgs_per_cu" give the
  * residency that box / triangle batches large enough for the cap run with, as the runtime's occupancy query
  * reports it for the launch configuration in use (0 = uncapped).  The cap is set through the amount of
  * dynamic LDS a launch asks for; the amount is verified against that query once per process, so a runtime

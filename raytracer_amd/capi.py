@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librt_dp.so")
+LIB_PATH = os.environ.get("RT_DP_LIB") or os.path.join(_HERE, "lib", "librt_dp.so")   # RT_DP_LIB: another build of the same library (A/B runs)
 
 OP_TRIANGLE, OP_QUADBOX, OP_EUCLIDEAN, OP_ANGULAR = 0, 1, 2, 3
 F_DEVICE_PTRS = 0x1

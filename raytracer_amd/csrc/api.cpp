@@ -1169,7 +1169,7 @@ int rt_dp_bvh4_build_device(rt_dp_ctx *ctx, const float *tris, uint32_t n_tris, 
 int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value) {
     if (!ctx || !key) return fail(RT_DP_ENULL, "rt_dp_set_option: NULL argument");
     if (!strcmp(key, "variant")) {
-        if (!(value == 0 || value == 10 || value == 21)) return fail(RT_DP_EINVAL, "variant must be 0, 10 or 21 (diagnostic shapes)");
+        if (!(value == 0 || value == 10 || value == 21 || value == 22)) return fail(RT_DP_EINVAL, "variant must be 0, 10, 21 or 22 (diagnostic shapes)");
         ctx->tuning.variant = value;
     } else if (!strcmp(key, "wgs_per_cu")) {
         if (!(value == 0 || value == 99 || (value >= 3 && value <= 16))) return fail(RT_DP_EINVAL, "wgs_per_cu must be 0 (default), 3..16, or 99 (no cap)");

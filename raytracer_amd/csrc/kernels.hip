@@ -228,10 +228,19 @@ __device__ __forceinline__ float quad_xor2(float v) {  // quad_perm [2,3,0,1]
 // First pair boundary (a beat index whose predecessor carries the reset bit; 0 and n count as boundaries) at or
 // after `nominal`, looked for in windows of 64 beats that start below `limit`; a value >= limit means that no
 // boundary lies in [nominal, limit).  Executed by one full wave; at most (limit - nominal) / 64 + 1 loads per lane.
-__device__ __forceinline__ uint64_t pair_boundary(const uint32_t *ctl, uint64_t nominal, uint64_t limit, uint64_t n, int lane) {
+__device__ __forceinline__ uint64_t pair_boundary(const uint32_t *ctl, uint64_t nominal, uint64_t limit, uint64_t n, int lane, uint32_t probe) {
     if (nominal == 0) return 0;
     if (nominal >= n) return n;
-    for (uint64_t i0 = nominal; i0 < limit; i0 += 64) {
+    {   // first window: the control words were fetched earlier (pair_probe), so that other loads could be issued meanwhile
+        const uint64_t i = nominal + lane;
+        const bool p = (i < n) ? (((probe >> 16) & 1u) != 0u) : true;
+        const unsigned long long m = __ballot(p);
+        if (m) {
+            const uint64_t r = nominal + (uint64_t)(__ffsll((long long)m) - 1);
+            return r < n ? r : n;
+        }
+    }
+    for (uint64_t i0 = nominal + 64; i0 < limit; i0 += 64) {
         const uint64_t i = i0 + lane;
         const bool p = (i < n) ? (((ctl[i - 1] >> 16) & 1u) != 0u) : true;  // indices >= n act as boundaries
         const unsigned long long m = __ballot(p);
@@ -241,6 +250,12 @@ __device__ __forceinline__ uint64_t pair_boundary(const uint32_t *ctl, uint64_t 
         }
     }
     return limit < n ? limit : n;  // not a boundary: only "none below limit"
+}
+
+// The control word pair_boundary's first window needs from this lane (issued early, consumed later).
+__device__ __forceinline__ uint32_t pair_probe(const uint32_t *ctl, uint64_t nominal, uint64_t n, int lane) {
+    const uint64_t i = nominal + lane;
+    return (nominal != 0 && i < n) ? ctl[i - 1] : 0u;
 }
 
 // The same without a limit, for the end of a vector pair that runs on beyond the tile after the one it started
@@ -266,55 +281,94 @@ __device__ __forceinline__ uint64_t pair_boundary_far(const uint32_t *ctl, uint6
     }
 }
 
-template <bool EUC, bool NT, int PASSES, int WALK>
-__global__ __launch_bounds__(256) void k_vec(VecArgs args, uint64_t n, uint32_t tile) {
+// A value every lane of the wave holds alike (read from LDS, hence in vector registers) moved to scalar registers:
+// the tile bounds and loop counters derived from it then cost no vector registers.
+__device__ __forceinline__ uint64_t wave_uniform(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Register budget: the angular shape with four load pairs per lane must stay within 72 VGPRs (7 waves per SIMD, 7
+// resident workgroups per CU); one register more drops it to 6 and costs about 5 % (measured), and squeezing it into
+// 64 for 8 waves makes the allocator spill inside the beat loop (0.56 of the HBM roof instead of 0.75).
+template <bool EUC, bool NT, int PASSES>
+__global__ __launch_bounds__(256, (PASSES <= 4) ? 7 : 4) void k_vec(VecArgs args, uint64_t n, uint32_t tile, int walk_mode) {
+    constexpr int kLook = 4;                 // beat sums fetched per LDS round trip by the long-pair walk
     constexpr int LPB = EUC ? 4 : 2;         // lanes per beat
     constexpr int BPP = kThreads / LPB;      // beats per pass
     constexpr int SUB = PASSES * BPP;        // beats per sub-tile
     constexpr int ROW = EUC ? 16 : 8;        // floats per beat and vector
 
-    __shared__ float s_sum0[SUB + WALK];
-    __shared__ float s_sum1[EUC ? 1 : SUB + WALK];
-    __shared__ uint32_t s_ctl[SUB + WALK];
-    __shared__ float s_out0[SUB + WALK];
-    __shared__ float s_out1[EUC ? 1 : SUB + WALK];
+    __shared__ float s_sum0[SUB + kLook];
+    __shared__ float s_sum1[EUC ? 1 : SUB + kLook];
+    __shared__ uint32_t s_ctl[SUB + kLook];
+    __shared__ float s_out0[SUB + kLook];
+    __shared__ float s_out1[EUC ? 1 : SUB + kLook];
     __shared__ uint64_t s_range[2];
     __shared__ float s_carry[2][2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // This workgroup owns the vector pairs that START in its nominal range [first, next).  Both searches are
-    // limited to one tile: a workgroup whose range holds no pair start leaves after tile / 64 loads per lane
-    // however long the pair that covers it is, and only a workgroup that owns a long pair looks further for
-    // its end -- over beats it then has to accumulate one by one anyway.
+    // This workgroup owns the vector pairs that START in its nominal range [first, next): its beats run from lo, the
+    // first pair boundary at or after first, to hi, the first pair boundary at or after next.  The operand loads of
+    // the first sub-tile are issued from `first` before lo and hi are known, so that the boundary searches (loads of
+    // control words, one memory round trip) overlap with them instead of preceding them; the few beats in front of
+    // lo belong to the previous workgroup's last pair and are dropped.  Both searches are limited to one tile: a
+    // workgroup whose range holds no pair start leaves after tile / 64 loads per lane however long the pair that
+    // covers it is, and only a workgroup that owns a long pair looks further for its end -- over beats it then has
+    // to accumulate one by one anyway.
+    //
+    // The overlap needs registers for the searches while the operand loads are in flight; the shapes with eight load
+    // pairs per lane run at four waves per SIMD and have them, the shapes that must stay within 72 registers would
+    // spill (measured on the angular default: 0.65 of the HBM roof instead of 0.75) and search first, then load from lo.
+    constexpr bool kOverlap = (PASSES >= 8);
     const uint64_t first = (uint64_t)blockIdx.x * tile, next = first + tile;
-    if (wave < 2) {
-        const uint64_t from = wave ? next : first;
-        const uint64_t r = pair_boundary(args.ctl, from, from + tile, n, lane);
-        if (lane == 0) s_range[wave] = r;
-    }
-    if (tid == 0) {
-        // only the workgroup that starts at beat 0 can inherit a running sum
-        s_carry[0][0] = (blockIdx.x == 0) ? args.state_in[0] : 0.0f;
-        s_carry[0][1] = (!EUC && blockIdx.x == 0) ? args.state_in[1] : 0.0f;
-    }
-    __syncthreads();
-    const uint64_t lo = s_range[0];
-    if (lo >= next || lo >= n) return;  // no pair starts here
-    uint64_t hi = s_range[1];
-    if (hi < n && hi >= next + tile) {  // the last pair that starts here runs on beyond the next tile (uniform branch)
-        __syncthreads();
-        if (wave == 0) {
-            const uint64_t r = pair_boundary_far(args.ctl, hi, n, lane);
-            if (lane == 0) s_range[1] = r;
-        }
-        __syncthreads();
-        hi = s_range[1];
-    }
-
     const int part = tid % LPB;  // which four elements of the beat
+    const uint32_t probe = (wave < 2) ? pair_probe(args.ctl, wave ? next : first, n, lane) : 0u;
+    uint64_t lo = first, hi = n;
+    bool long_pair = false;
+
+    // lo, hi and the kind of walk from the two searches; false: no pair starts in this workgroup's range
+    auto search = [&]() {
+        if (wave < 2) {
+            const uint64_t from = wave ? next : first;
+            const uint64_t r = pair_boundary(args.ctl, from, from + tile, n, lane, probe);
+            if (lane == 0) s_range[wave] = r;
+        }
+        if (tid == 0) {
+            // only the workgroup that starts at beat 0 can inherit a running sum
+            s_carry[0][0] = (blockIdx.x == 0) ? args.state_in[0] : 0.0f;
+            s_carry[0][1] = (!EUC && blockIdx.x == 0) ? args.state_in[1] : 0.0f;
+        }
+    };
+    auto resolve = [&]() -> bool {   // behind a barrier that follows search()
+        lo = wave_uniform(s_range[0]);
+        if (lo >= next || lo >= n) return false;
+        hi = wave_uniform(s_range[1]);
+        if (hi < n && hi >= next + tile) {  // the last pair that starts here runs on beyond the next tile (uniform branch)
+            __syncthreads();
+            if (wave == 0) {
+                const uint64_t r = pair_boundary_far(args.ctl, hi, n, lane);
+                if (lane == 0) s_range[1] = r;
+            }
+            __syncthreads();
+            hi = wave_uniform(s_range[1]);
+        }
+        // a vector pair of more than four tiles is in this range (uniform); variant 21 / 22 force one walk or the other (A/B)
+        long_pair = (walk_mode == 0) ? (hi - lo > 4ull * tile + (uint64_t)tile) : (walk_mode == 2);
+        return true;
+    };
+    if (!kOverlap) {
+        search();
+        __syncthreads();
+        if (!resolve()) return;
+    }
+    const uint64_t start = kOverlap ? first : lo;
     int par = 0;
-    for (uint64_t base = lo; base < hi; base += SUB, par ^= 1) {
-        const int cnt = (hi - base < (uint64_t)SUB) ? (int)(hi - base) : SUB;
+    for (uint64_t base = start;; base += SUB, par ^= 1) {
+        const bool head = (base == start);            // first sub-tile
+        const bool pending = kOverlap && head;        // ... whose lo and hi are still being looked for
+        const uint64_t left = (pending ? n : hi) - base;
+        const int loaded = (left < (uint64_t)SUB) ? (int)left : SUB;
 
         // phase 1: tree sums of this sub-tile's beats
         f4v va[PASSES], vb[PASSES];
@@ -322,7 +376,7 @@ __global__ __launch_bounds__(256) void k_vec(VecArgs args, uint64_t n, uint32_t 
 #pragma unroll
         for (int u = 0; u < PASSES; ++u) {
             const int bl = u * BPP + tid / LPB;
-            if (bl < cnt) {
+            if (bl < loaded) {
                 const uint64_t e = (base + bl) * ROW + part * 4;
                 va[u] = ld<f4v, NT>(args.a + e);
                 vb[u] = ld<f4v, NT>(args.b + e);
@@ -331,6 +385,7 @@ __global__ __launch_bounds__(256) void k_vec(VecArgs args, uint64_t n, uint32_t 
                 va[u] = (f4v)(0.0f); vb[u] = (f4v)(0.0f); vc[u] = 0u;
             }
         }
+        if (pending) search();
 #pragma unroll
         for (int u = 0; u < PASSES; ++u) {
             const int bl = u * BPP + tid / LPB;
@@ -362,55 +417,91 @@ __global__ __launch_bounds__(256) void k_vec(VecArgs args, uint64_t n, uint32_t 
                 r0 = (s0[0] + s0[2]) + (s0[1] + s0[3]);
                 r1 = (s1[0] + s1[2]) + (s1[1] + s1[3]);
             }
-            if (part == 0 && bl < cnt) {
+            if (part == 0 && bl < loaded) {
                 s_sum0[bl] = r0;
                 if (!EUC) s_sum1[bl] = r1;
                 s_ctl[bl] = vc[u];
             }
         }
         __syncthreads();
+        if (pending && !resolve()) return;  // no pair starts here
+        // beats of this sub-tile that are ours: [own, cnt); own > 0 only in front of lo
+        const int cnt = (hi - base < (uint64_t)loaded) ? (int)(hi - base) : loaded;
+        const int own = (lo > base) ? ((lo - base < (uint64_t)cnt) ? (int)(lo - base) : cnt) : 0;
+        // the register entering beat 0 of the sub-tile is the carry of the previous one when a pair runs on across
+        // the border, and what the stream handed over (s_carry[0], set above) when the first sub-tile starts a pair
+        const bool carry_in = (base > lo) || head;
 
-        // phase 2: one lane per vector pair accumulates its beats in order.  The chain acc -> acc + sum is serial
-        // by definition, but the sums and control words do not depend on it: WALK of them are fetched from LDS per
-        // round trip (the arrays are padded, so the look-ahead past a pair's end or past cnt stays in bounds and
-        // is simply not used).
-        for (int t0 = tid; t0 < cnt; t0 += kThreads) {
-            const bool starts = (t0 == 0) || (((s_ctl[t0 - 1] >> 16) & 1u) != 0u);
-            if (starts) {
-                float acc0 = (t0 == 0) ? s_carry[par][0] : 0.0f;
-                float acc1 = (t0 == 0) ? s_carry[par][1] : 0.0f;
-                int i = t0;
-                bool more = true;
-                while (more) {
-                    float v0[WALK], v1[WALK];
-                    uint32_t c[WALK];
-#pragma unroll
-                    for (int k = 0; k < WALK; ++k) {
-                        v0[k] = s_sum0[i + k];
-                        if (!EUC) v1[k] = s_sum1[i + k];
-                        c[k] = s_ctl[i + k];
-                    }
-#pragma unroll
-                    for (int k = 0; k < WALK; ++k) {
-                        if (more) {
-                            const bool rs = ((c[k] >> 16) & 1u) != 0u;
-                            const float o0 = acc0 + v0[k];
-                            s_out0[i + k] = canon_nan(o0);
-                            acc0 = rs ? 0.0f : o0;
-                            if (!EUC) {
-                                const float o1 = acc1 + v1[k];
-                                s_out1[i + k] = canon_nan(o1);
-                                acc1 = rs ? 0.0f : o1;
-                            }
-                            const bool last = (i + k + 1 == cnt);
-                            if (last) {  // exactly one lane reaches the end of the sub-tile
-                                s_carry[par ^ 1][0] = acc0;
-                                s_carry[par ^ 1][1] = acc1;
-                            }
-                            more = !rs && !last;
+        // phase 2: one lane per vector pair accumulates its beats in order.  Ordinary streams (pairs of a few beats)
+        // take the plain loop: one beat per LDS round trip, least instructions, and the round trips hide behind the
+        // other workgroups of the CU.  A workgroup that owns a long pair is alone with a serial chain; there the
+        // look-ahead form fetches four beat sums per round trip (the arrays are padded, so the look-ahead past a
+        // pair's end or past cnt stays in bounds and is simply not used).  The choice is uniform over the workgroup.
+        if (!long_pair) {
+            for (int t0 = tid; t0 < cnt; t0 += kThreads) {
+                const bool starts = (t0 >= own) && ((t0 == 0) || (((s_ctl[t0 - 1] >> 16) & 1u) != 0u));
+                if (starts) {
+                    float acc0 = (t0 == 0 && carry_in) ? s_carry[par][0] : 0.0f;
+                    float acc1 = (t0 == 0 && carry_in) ? s_carry[par][1] : 0.0f;
+                    int i = t0;
+                    bool rs;
+                    do {
+                        const float o0 = acc0 + s_sum0[i];
+                        s_out0[i] = canon_nan(o0);
+                        rs = ((s_ctl[i] >> 16) & 1u) != 0u;
+                        acc0 = rs ? 0.0f : o0;
+                        if (!EUC) {
+                            const float o1 = acc1 + s_sum1[i];
+                            s_out1[i] = canon_nan(o1);
+                            acc1 = rs ? 0.0f : o1;
                         }
+                        ++i;
+                    } while (i < cnt && !rs);
+                    if (i == cnt) {  // exactly one lane reaches the end of the sub-tile
+                        s_carry[par ^ 1][0] = acc0;
+                        s_carry[par ^ 1][1] = acc1;
                     }
-                    i += WALK;
+                }
+            }
+        } else {
+            for (int t0 = tid; t0 < cnt; t0 += kThreads) {
+                const bool starts = (t0 >= own) && ((t0 == 0) || (((s_ctl[t0 - 1] >> 16) & 1u) != 0u));
+                if (starts) {
+                    float acc0 = (t0 == 0 && carry_in) ? s_carry[par][0] : 0.0f;
+                    float acc1 = (t0 == 0 && carry_in) ? s_carry[par][1] : 0.0f;
+                    int i = t0;
+                    bool more = true;
+                    while (more) {
+                        float v0[kLook], v1[kLook];
+                        uint32_t c[kLook];
+#pragma unroll
+                        for (int k = 0; k < kLook; ++k) {
+                            v0[k] = s_sum0[i + k];
+                            if (!EUC) v1[k] = s_sum1[i + k];
+                            c[k] = s_ctl[i + k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < kLook; ++k) {
+                            if (more) {
+                                const bool rs = ((c[k] >> 16) & 1u) != 0u;
+                                const float o0 = acc0 + v0[k];
+                                s_out0[i + k] = canon_nan(o0);
+                                acc0 = rs ? 0.0f : o0;
+                                if (!EUC) {
+                                    const float o1 = acc1 + v1[k];
+                                    s_out1[i + k] = canon_nan(o1);
+                                    acc1 = rs ? 0.0f : o1;
+                                }
+                                const bool last = (i + k + 1 == cnt);
+                                if (last) {
+                                    s_carry[par ^ 1][0] = acc0;
+                                    s_carry[par ^ 1][1] = acc1;
+                                }
+                                more = !rs && !last;
+                            }
+                        }
+                        i += kLook;
+                    }
                 }
             }
         }
@@ -418,13 +509,16 @@ __global__ __launch_bounds__(256) void k_vec(VecArgs args, uint64_t n, uint32_t 
 
         // phase 3: coalesced result store
         for (int t0 = tid; t0 < cnt; t0 += kThreads) {
-            st<float, NT>(args.out0 + base + t0, s_out0[t0]);
-            if (!EUC) st<float, NT>(args.out1 + base + t0, s_out1[t0]);
+            if (t0 >= own) {
+                st<float, NT>(args.out0 + base + t0, s_out0[t0]);
+                if (!EUC) st<float, NT>(args.out1 + base + t0, s_out1[t0]);
+            }
         }
+        if (base + SUB >= hi) break;
     }
-    if (hi == n && tid == 0) {  // the workgroup that owns the last beat hands the registers on
-        args.state_out[0] = canon_nan(s_carry[par][0]);
-        if (!EUC) args.state_out[1] = canon_nan(s_carry[par][1]);
+    if (hi == n && tid == 0) {  // the workgroup that owns the last beat hands the registers on (written by its last walk)
+        args.state_out[0] = canon_nan(s_carry[par ^ 1][0]);
+        if (!EUC) args.state_out[1] = canon_nan(s_carry[par ^ 1][1]);
     }
 }
 
@@ -632,32 +726,29 @@ hipError_t launch_tri(const TriArgs &args, uint64_t n, const Tuning &t, hipStrea
     return hipGetLastError();
 }
 
-template <bool EUC, bool NT, int WALK> static void launch_vec_w(const VecArgs &args, uint64_t n, uint32_t tile, int passes, unsigned blocks, unsigned lds,
-                                                                hipStream_t stream) {
-    switch (passes) {
-    case 2: hipLaunchKernelGGL((k_vec<EUC, NT, 2, WALK>), dim3(blocks), dim3(kThreads), lds, stream, args, n, tile); break;
-    case 8: hipLaunchKernelGGL((k_vec<EUC, NT, 8, WALK>), dim3(blocks), dim3(kThreads), lds, stream, args, n, tile); break;
-    default: hipLaunchKernelGGL((k_vec<EUC, NT, 4, WALK>), dim3(blocks), dim3(kThreads), lds, stream, args, n, tile); break;
-    }
-}
-
 template <bool EUC, bool NT> static void launch_vec_p(const VecArgs &args, uint64_t n, uint32_t tile, int passes, int walk, unsigned blocks, unsigned lds,
                                                       hipStream_t stream) {
-    if (walk == 1) launch_vec_w<EUC, NT, 1>(args, n, tile, passes, blocks, lds, stream);
-    else launch_vec_w<EUC, NT, 4>(args, n, tile, passes, blocks, lds, stream);
+    switch (passes) {
+    case 2: hipLaunchKernelGGL((k_vec<EUC, NT, 2>), dim3(blocks), dim3(kThreads), lds, stream, args, n, tile, walk); break;
+    case 8: hipLaunchKernelGGL((k_vec<EUC, NT, 8>), dim3(blocks), dim3(kThreads), lds, stream, args, n, tile, walk); break;
+    default: hipLaunchKernelGGL((k_vec<EUC, NT, 4>), dim3(blocks), dim3(kThreads), lds, stream, args, n, tile, walk); break;
+    }
 }
 
 template <bool EUC> static hipError_t launch_vec(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    // defaults from an interleaved sweep on MI355X: sub-tile == tile == 512 beats for both opcodes
+    // defaults from interleaved sweeps on MI355X: sub-tiles of 512 beats for both opcodes; the Euclidean shape (loads
+    // issued from the nominal start) wants the nominal tile equal to the sub-tile, the angular shape (loads from the
+    // first pair boundary) a tile a few beats shorter, so that the pair that hangs over the nominal end still fits
+    // the one sub-tile (504: 0.749 of the HBM roof against 0.738 with 512)
     const int passes = (t.vec_passes == 2 || t.vec_passes == 4 || t.vec_passes == 8) ? t.vec_passes : (EUC ? 8 : 4);
-    uint32_t tile = t.vec_tile > 0 ? (uint32_t)t.vec_tile : 512u;
+    uint32_t tile = t.vec_tile > 0 ? (uint32_t)t.vec_tile : (EUC ? 512u : 504u);
     if (tile < 64u) tile = 64u;
     const uint64_t blocks = (n + tile - 1) / tile;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const unsigned lds = residency_lds(reinterpret_cast<const void *>(&k_vec<EUC, true, EUC ? 8 : 4, 4>), EUC ? kSlotEuc : kSlotAng, t.wgs_per_cu, kVecWgsPerCu,
+    const unsigned lds = residency_lds(reinterpret_cast<const void *>(&k_vec<EUC, true, EUC ? 8 : 4>), EUC ? kSlotEuc : kSlotAng, t.wgs_per_cu, kVecWgsPerCu,
                                        8192u + 64u);  // the kernel's own LDS stays below 8 KiB
-    const int walk = (t.variant == 21) ? 1 : 4;  // variant 21 (A/B only): one LDS round trip per beat of the serial walk
+    const int walk = (t.variant == 21) ? 1 : (t.variant == 22) ? 2 : 0;  // A/B only: 21 plain walk everywhere, 22 look-ahead walk everywhere
     if (use_nt(t)) launch_vec_p<EUC, true>(args, n, tile, passes, walk, (unsigned)blocks, lds, stream);
     else launch_vec_p<EUC, false>(args, n, tile, passes, walk, (unsigned)blocks, lds, stream);
     return hipGetLastError();

@@ -167,5 +167,6 @@ for op, (prefix, total, rd, wr) in UNITS.items():
     lines.append("| %s | %.0f | %.1f | %.3f | %.2f GHz |" % (op, iv[0] / wv[0], iv[0] * 64 / units_log[op], frac, clk))
     traffic[op]["valu_issue_fraction"] = round(frac, 4)
 open(os.path.join(PROF, tag + "_pmc.md"), "w").write("\n".join(lines) + "\n")
+traffic["_source"] = "rocprofv3 --pmc passes %s: FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU, one counter set per run" % tag
 json.dump(traffic, open(os.path.join(PROF, "traffic.json"), "w"), indent=1, sort_keys=True)
 print("\n".join(lines))

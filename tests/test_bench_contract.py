@@ -13,14 +13,17 @@ FIELDS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
           "data", "config", "roofline", "cpu_baseline"]
 
 
-def check_line(out, n_gpus, steps, warmup):
+SMALL = ["--strong-log2-ops", "20", "--knn-log2-points", "14", "--knn-log2-queries", "10"]   # the default line's extras at test size
+
+
+def check_line(out, n_gpus, steps, warmup, scaling="weak"):
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out[-2000:]
     d = json.loads(lines[0])
     for f in FIELDS:
         assert f in d, f
     assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["scaling"] == scaling and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
@@ -46,11 +49,13 @@ def test_two_rank_rehearsal_line():
     s.close()
     env = dict(os.environ, RT_DP_REHEARSE_ONE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--log2-ops", "20"]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--log2-ops", "20"] + SMALL
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = check_line(r.stdout, 2, 3, 1)
-    assert d["cpu_baseline"] is None and set(d["per_opcode"]) == {"box", "tri", "euclid", "angular", "mixed"}
+    assert d["cpu_baseline"] is None
+    assert set(d["per_opcode"]) == {"box", "tri", "euclid", "angular", "mixed", "box_edge", "tri_edge", "mixed_2p20", "knn"}
+    assert d["per_opcode"]["mixed_2p20"]["scaling"] == "strong" and d["per_opcode"]["knn"]["leaf_major"]["scaling"] == "strong"
 
 
 @pytest.mark.gpu
@@ -59,8 +64,27 @@ def test_plain_gpus_flag_starts_the_ranks_itself():
     two ranks as a child process and relays rank 0's line."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["RT_DP_REHEARSE_ONE_GPU"] = "1"
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--log2-ops", "20"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--log2-ops", "20"] + SMALL
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = check_line(r.stdout, 2, 3, 1)
     assert d["cpu_baseline"] is None
+    assert "torch.distributed.run" not in " ".join(cmd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gpus", [1, 2, 3])
+def test_sharded_mixed_stream_reassembles_to_the_whole_stream(gpus):
+    """--only mixed --strong: one stream cut by shard.plan into one pair-aligned shard per rank; with --verify the shards'
+    results, put together in rank order, are compared on rank 0 with the whole stream evaluated in one batch -- all through
+    the HIP path (the ranks of this rehearsal share the one GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RT_DP_REHEARSE_ONE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--only", "mixed", "--strong",
+           "--strong-log2-ops", "19", "--verify"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = check_line(r.stdout, gpus, 2, 1, scaling="strong")
+    assert d["verified_against_whole_stream"] is True
+    c = d["config"]
+    assert c["units_whole_job"] >= (1 << 19) - 64 and (gpus == 1) == (c["units_this_gpu"] == c["units_whole_job"])
