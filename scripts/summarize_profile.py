@@ -123,7 +123,8 @@ for line in open(os.path.join(src, "log.txt")):
         except Exception:
             continue
         for k, v in d.get("per_opcode", {}).items():
-            units_log[k] = v["units_per_gpu"]
+            if "units_per_gpu" in v:
+                units_log[k] = v["units_per_gpu"]
 for op, (prefix, total, rd, wr) in UNITS.items():
     fe = {k: v for k, v in pmc("pmc_fetch_%s/*/*counter_collection.csv" % op, "FETCH_SIZE").items() if k[0].startswith(prefix)}
     we = {k: v for k, v in pmc("pmc_write_%s/*/*counter_collection.csv" % op, "WRITE_SIZE").items() if k[0].startswith(prefix)}
