@@ -445,21 +445,22 @@ __global__ __launch_bounds__(256, (PASSES <= 4) ? 7 : 4) void k_vec(VecArgs args
                     float acc1 = (t0 == 0 && carry_in) ? s_carry[par][1] : 0.0f;
                     int i = t0;
                     bool rs;
+                    // the loop body is the whole cost of this phase (few lanes are active, every wave pays for the longest
+                    // pair it holds), so it carries nothing that can wait: NaN results are made canonical when the sub-tile
+                    // is stored, and the reset only matters to what is handed on
                     do {
-                        const float o0 = acc0 + s_sum0[i];
-                        s_out0[i] = canon_nan(o0);
+                        acc0 = acc0 + s_sum0[i];
+                        s_out0[i] = acc0;
                         rs = ((s_ctl[i] >> 16) & 1u) != 0u;
-                        acc0 = rs ? 0.0f : o0;
                         if (!EUC) {
-                            const float o1 = acc1 + s_sum1[i];
-                            s_out1[i] = canon_nan(o1);
-                            acc1 = rs ? 0.0f : o1;
+                            acc1 = acc1 + s_sum1[i];
+                            s_out1[i] = acc1;
                         }
                         ++i;
                     } while (i < cnt && !rs);
                     if (i == cnt) {  // exactly one lane reaches the end of the sub-tile
-                        s_carry[par ^ 1][0] = acc0;
-                        s_carry[par ^ 1][1] = acc1;
+                        s_carry[par ^ 1][0] = rs ? 0.0f : acc0;
+                        s_carry[par ^ 1][1] = rs ? 0.0f : acc1;
                     }
                 }
             }
@@ -485,11 +486,11 @@ __global__ __launch_bounds__(256, (PASSES <= 4) ? 7 : 4) void k_vec(VecArgs args
                             if (more) {
                                 const bool rs = ((c[k] >> 16) & 1u) != 0u;
                                 const float o0 = acc0 + v0[k];
-                                s_out0[i + k] = canon_nan(o0);
+                                s_out0[i + k] = o0;
                                 acc0 = rs ? 0.0f : o0;
                                 if (!EUC) {
                                     const float o1 = acc1 + v1[k];
-                                    s_out1[i + k] = canon_nan(o1);
+                                    s_out1[i + k] = o1;
                                     acc1 = rs ? 0.0f : o1;
                                 }
                                 const bool last = (i + k + 1 == cnt);
@@ -510,8 +511,8 @@ __global__ __launch_bounds__(256, (PASSES <= 4) ? 7 : 4) void k_vec(VecArgs args
         // phase 3: coalesced result store
         for (int t0 = tid; t0 < cnt; t0 += kThreads) {
             if (t0 >= own) {
-                st<float, NT>(args.out0 + base + t0, s_out0[t0]);
-                if (!EUC) st<float, NT>(args.out1 + base + t0, s_out1[t0]);
+                st<float, NT>(args.out0 + base + t0, canon_nan(s_out0[t0]));
+                if (!EUC) st<float, NT>(args.out1 + base + t0, canon_nan(s_out1[t0]));
             }
         }
         if (base + SUB >= hi) break;
