@@ -3,7 +3,7 @@
 OUT=gpurun_out/vec_ab_bisect.txt
 mkdir -p gpurun_out; : > $OUT
 one() { local label=$1; local w=$2; shift; shift
-  timeout -k 10 150 python bench.py --only $w --steps 200 --warmup 100 --no-cpu-baseline "$@" 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-44s kernel_ms %8.4f frac %.4f' % ('$label', r['per_opcode']['$w']['kernel_ms'], r['roofline']['frac']))" >> $OUT || { echo "FAILED $label" >> $OUT; exit 1; }
+  timeout -k 10 150 python bench.py --only $w --steps 200 --warmup 100 --no-cpu-baseline --log2-ops ${LOG2:-24} "$@" 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-44s kernel_ms %8.4f frac %.4f' % ('$label', r['per_opcode']['$w']['kernel_ms'], r['roofline']['frac']))" >> $OUT || { echo "FAILED $label" >> $OUT; exit 1; }
 }
 for rep in 1 2; do
   for w in angular euclid; do
