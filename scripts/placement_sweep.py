@@ -20,7 +20,11 @@ def main():
     sizes = [int(x) for x in sys.argv[1:]] or [24, 26]
     extras_kib = sorted(set([0] + [(m << k) for k in range(0, 18) for m in (1, 3)] + [65536 + 4, 65536 + 64, 2048 + 4, 2048 + 64]))
     extras_kib = [e for e in extras_kib if e <= 196608]
+    if os.environ.get("SWEEP_FEW"):
+        extras_kib = [0, 1, 4, 12, 64, 512, 1024, 2052, 4096, 16384, 65536, 65540, 131072]
     ctx = capi.Context(device=0)
+    ctx.set_tuning(int(os.environ.get("SWEEP_OPS_PER_LANE", "0")), 0, 0)
+    ctx.set_option("wgs_per_cu", int(os.environ.get("SWEEP_WGS", "0")))
     stream = torch.cuda.Stream()
     for lg in sizes:
         n = 1 << lg if lg < 40 else lg
