@@ -519,9 +519,12 @@ int rt_dp_bvh4_build_device(rt_dp_ctx *ctx, const float *tris, uint32_t n_tris, 
 int rt_dp_set_tuning(rt_dp_ctx *ctx, int ops_per_lane, int nontemporal, int vec_tile);
 /* Further integer knobs by name: "vec_passes" (opcodes 2/3: 16-byte load pairs in flight per
  * lane and sub-tile, 2 / 4 / 8), "variant" (0 normal; 10 diagnostic: the box kernel's memory
- * pattern without its arithmetic, outputs meaningless; 21 / 22 A/B: the beat kernels' serial accumulation
- * with one beat sum per LDS round trip everywhere / with four everywhere; by default a workgroup that owns a
- * vector pair longer than four tiles takes the second form, all others the first; results identical).  Environment: RT_DP_VEC_PASSES,
+ * pattern without its arithmetic, outputs meaningless; the beat kernels have two shapes with identical results -- "owning": a workgroup owns whole vector
+ * pairs and searches for their boundaries; "chained": fixed tiles that hand their running sums on from one to the
+ * next through a workspace inside the context -- and each opcode defaults to the one that measured faster (Euclidean
+ * chained, angular owning); 23: owning for both (21 / 22: with one or the other form of its serial accumulation),
+ * 27: chained for both, 24 / 25 diagnostic: chained without the accumulation / without the LDS stage either,
+ * outputs meaningless).  "vec_tile" applies to the owning shape only.  Environment: RT_DP_VEC_PASSES,
  * RT_DP_VARIANT.  "wgs_per_cu" (resident 256-thread workgroups per CU of the box / triangle / beat
  * kernels: 0 the measured per-kernel default, 3..16, 99 as many as fit; environment RT_DP_WGS_PER_CU).
  * "stream_mode" selects how rt_dp_eval_bundles_device works: 1 partitions the
@@ -535,6 +538,9 @@ int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value);
  * dynamic LDS a launch asks for; the amount is verified against that query once per process, so a runtime
  * that hands out LDS differently shows up here instead of silently changing the residency.              */
 int rt_dp_get_option(rt_dp_ctx *ctx, const char *key, int *value);
+/* "vec_chain_giveups" (read only): hand-overs between tiles of the beat kernels that were given up on after a
+ * bounded wait since the context's workspace was last (re)allocated; anything but 0 means the device lost a
+ * workgroup and the beat results of that launch are not to be trusted.                                        */
 
 const char *rt_dp_last_error(void);
 const char *rt_dp_version(void);

@@ -70,6 +70,13 @@ struct rt_dp_ctx {
     // accumulator registers on the context's own stream (or from the host) waits for it first
     hipEvent_t launched = nullptr;
     bool launched_pending = false;
+    // hand-over words of the chained beat kernels (kernels.hip); grows, is zero when allocated and never cleared:
+    // a word is valid for the launch whose epoch it carries.  A buffer that was outgrown may still be in use by a
+    // launch on a caller's stream, so it is kept until the context goes.
+    char *d_chain = nullptr;
+    size_t chain_bytes = 0;
+    uint32_t chain_epoch = 0;
+    std::vector<char *> chain_retired;
     Tuning tuning{0, 0, 0, 0, 0, 0};
     int stream_mode = 0;  // record streams in HBM: 0 automatic, 1 partition by opcode first, 2 fused single pass
 };
@@ -183,6 +190,28 @@ int join_caller_stream(rt_dp_ctx *ctx, bool host_too) {
     return RT_DP_OK;
 }
 
+// The chained beat kernels' workspace for a segment of n beats and a fresh epoch, on stream s.
+int chain_for(rt_dp_ctx *ctx, uint64_t n, hipStream_t s, VecArgs &a) {
+    const size_t need = vec_chain_bytes(n);
+    if (need > ctx->chain_bytes) {
+        const size_t want = need + need / 4;
+        char *fresh = nullptr;
+        hipError_t e = hipMalloc(&fresh, want);
+        if (e != hipSuccess) return fail(RT_DP_ENOMEM, "hipMalloc(%zu) for the beat kernels' hand-over words failed: %s", want, hipGetErrorString(e));
+        if (ctx->d_chain) ctx->chain_retired.push_back(ctx->d_chain);
+        ctx->d_chain = fresh;
+        ctx->chain_bytes = want;
+        HIP_TRY(hipMemsetAsync(fresh, 0, want, s));
+    }
+    if (++ctx->chain_epoch == 0) {  // 2^32 launches later: start over with clean words
+        HIP_TRY(hipMemsetAsync(ctx->d_chain, 0, ctx->chain_bytes, s));
+        ctx->chain_epoch = 1;
+    }
+    a.chain = reinterpret_cast<unsigned long long *>(ctx->d_chain);
+    a.epoch = ctx->chain_epoch;
+    return RT_DP_OK;
+}
+
 // Enqueue the kernels of one batch whose arrays are all device pointers.
 int launch_device(rt_dp_ctx *ctx, const rt_dp_op_batch *in, const rt_dp_result_batch *out, hipStream_t s) {
     const uint64_t n_tri = in->n[RT_DP_OP_TRIANGLE], n_box = in->n[RT_DP_OP_QUADBOX];
@@ -214,10 +243,14 @@ int launch_device(rt_dp_ctx *ctx, const rt_dp_op_batch *in, const rt_dp_result_b
         HIP_TRY(hipMemcpyAsync(nxt, cur, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (n_euc) {
             VecArgs a{in->euc.a, in->euc.b, in->euc.ctl, out->euc.accumulator, nullptr, cur + 0, nxt + 0};
+            int rc = chain_for(ctx, n_euc, s, a);
+            if (rc != RT_DP_OK) return rc;
             HIP_TRY(launch_euclid(a, n_euc, ctx->tuning, s));
         }
         if (n_ang) {
             VecArgs a{in->ang.a, in->ang.b, in->ang.ctl, out->ang.dot_product, out->ang.norm, cur + 1, nxt + 1};
+            int rc = chain_for(ctx, n_ang, s, a);
+            if (rc != RT_DP_OK) return rc;
             HIP_TRY(launch_angular(a, n_ang, ctx->tuning, s));
         }
         ctx->cur ^= 1;
@@ -426,6 +459,8 @@ void rt_dp_destroy(rt_dp_ctx *ctx) {
     for (char *q : ctx->d_knn)
         if (q) (void)hipFree(q);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
+    if (ctx->d_chain) (void)hipFree(ctx->d_chain);
+    for (char *old_chain : ctx->chain_retired) (void)hipFree(old_chain);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (g_default_ctx.p == ctx) g_default_ctx.p = nullptr;
     delete ctx;
@@ -1169,7 +1204,7 @@ int rt_dp_bvh4_build_device(rt_dp_ctx *ctx, const float *tris, uint32_t n_tris, 
 int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value) {
     if (!ctx || !key) return fail(RT_DP_ENULL, "rt_dp_set_option: NULL argument");
     if (!strcmp(key, "variant")) {
-        if (!(value == 0 || value == 10 || value == 21 || value == 22)) return fail(RT_DP_EINVAL, "variant must be 0, 10, 21 or 22 (diagnostic shapes)");
+        if (!(value == 0 || value == 10 || (value >= 21 && value <= 27 && value != 26))) return fail(RT_DP_EINVAL, "variant must be 0, 10, 21..25 or 27 (diagnostic shapes)");
         ctx->tuning.variant = value;
     } else if (!strcmp(key, "wgs_per_cu")) {
         if (!(value == 0 || value == 99 || (value >= 3 && value <= 16))) return fail(RT_DP_EINVAL, "wgs_per_cu must be 0 (default), 3..16, or 99 (no cap)");
@@ -1197,7 +1232,14 @@ int rt_dp_get_option(rt_dp_ctx *ctx, const char *key, int *value) {
     else if (!strcmp(key, "ops_per_lane")) *value = ctx->tuning.ops_per_lane ? ctx->tuning.ops_per_lane : 1;
     else if (!strcmp(key, "nontemporal")) *value = ctx->tuning.nontemporal == 2 ? 0 : 1;
     else if (!strcmp(key, "vec_tile")) *value = ctx->tuning.vec_tile > 0 ? (ctx->tuning.vec_tile < 64 ? 64 : ctx->tuning.vec_tile) : 512;
-    else if (!strcmp(key, "box_wgs_per_cu")) *value = resolved_residency(ctx->tuning, true);
+    else if (!strcmp(key, "vec_chain_giveups")) {
+        unsigned long long h = 0;
+        if (ctx->d_chain) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipMemcpy(&h, ctx->d_chain, sizeof h, hipMemcpyDeviceToHost));
+        }
+        *value = h > 0x7FFFFFFFull ? 0x7FFFFFFF : (int)h;
+    } else if (!strcmp(key, "box_wgs_per_cu")) *value = resolved_residency(ctx->tuning, true);
     else if (!strcmp(key, "tri_wgs_per_cu")) *value = resolved_residency(ctx->tuning, false);
     else return fail(RT_DP_EINVAL, "unknown option '%s'", key);
     return RT_DP_OK;

@@ -31,7 +31,17 @@ struct VecArgs {
     float *out1;          // unused / angular_norm
     const float *state_in;  // accumulator register(s) entering beat 0: [1] Euclidean, [2] angular
     float *state_out;       // accumulator register(s) after the last beat
+    // hand-over of the running sums from tile to tile (the chained shape of the beat kernels): vec_chain_bytes(n) bytes,
+    // zero when allocated and never cleared afterwards; a slot is valid for the launch whose `epoch` it carries.
+    // NULL selects the shape that needs no workspace.
+    unsigned long long *chain = nullptr;
+    uint32_t epoch = 0;
+    uint32_t diag = 0;  // diagnostic shapes of the chained kernel (A/B only, results meaningless): 1 no accumulation walk, 2 no LDS stage either
 };
+
+// Workspace of the chained beat kernels for n beats (any PASSES): a 256-byte header (word 0 counts hand-overs that
+// were given up on, which never happens unless the device loses a workgroup) and 16 bytes per 128-beat tile.
+size_t vec_chain_bytes(uint64_t n);
 
 struct RayPrepArgs {
     const float *dir[3];

@@ -523,6 +523,231 @@ __global__ __launch_bounds__(256, (PASSES <= 4) ? 7 : 4) void k_vec(VecArgs args
     }
 }
 
+// ---- the chained shape -----------------------------------------------------------------------------------------
+// Fixed tiles: workgroup b evaluates beats [b * SUB, (b + 1) * SUB) and nothing else -- no search for pair
+// boundaries, no second sub-tile for the pair that hangs over the end, no operand loaded twice.  The one pair that
+// enters a tile from the previous one is continued from the running sums the previous workgroup publishes when its
+// walk reaches the end of its tile: one 64-bit word per sum, {launch epoch, float bits}, written and polled with
+// device-scope atomics, so a word is valid exactly when it carries this launch's epoch and nothing has to be cleared
+// between launches.  Only the lane that continues that pair waits; every other pair of the tile starts from +0 and is
+// walked meanwhile.  The arithmetic is the same strictly sequential sum in the same order (the continuing lane adds
+// its beats one by one onto the value it received), so the results do not depend on the shape.
+//
+// Progress: a workgroup waits only for the workgroup with the next lower index, which was dispatched before it and
+// waits, if at all, for a still lower one; workgroup 0 never waits.  A pair spanning many tiles is a serial chain by
+// definition of the arithmetic and costs one walk per tile, one after the other.  The wait is bounded all the same
+// (a lost workgroup must not hang the device): after kChainSpins polls the lane counts a give-up in the workspace
+// header and goes on with +0.
+constexpr int kChainSpins = 1 << 20;  // about a second; the longest legitimate wait is tens of milliseconds
+
+__device__ __forceinline__ unsigned long long chain_word(uint32_t epoch, float v) {
+    return ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v);
+}
+
+__device__ __forceinline__ float chain_wait(unsigned long long *slot, uint32_t epoch, unsigned long long *header) {
+    for (int spin = 0; spin < kChainSpins; ++spin) {
+        const unsigned long long w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(w >> 32) == epoch) return __uint_as_float((uint32_t)w);
+        __builtin_amdgcn_s_sleep(4);
+    }
+    atomicAdd(header, 1ull);
+    return 0.0f;
+}
+
+template <int EPL> struct VecLoad;
+template <> struct VecLoad<4> { using T = f4v; };
+template <> struct VecLoad<2> { using T = f2v; };
+
+// EPL: elements of a beat per lane = width of the operand loads (4: 16-byte loads; 2: 8-byte loads, with which the
+// angular beat spreads over four lanes like the Euclidean one and its adder tree gains the same lane-xor-2 level in
+// front -- measured no faster, 0.746 against 0.743 of the HBM roof, and not instantiated).
+template <bool EUC, bool NT, int PASSES, int EPL>
+__global__ __launch_bounds__(256, (PASSES * EPL <= 16) ? 7 : 4) void k_vec_chain(VecArgs args, uint64_t n) {
+    static_assert(EPL == 4 || (EPL == 2 && !EUC), "the Euclidean beat needs all four lanes of a quad at EPL = 4");
+    using VT = typename VecLoad<EPL>::T;
+    constexpr int kLook = 4;                 // beat sums fetched per LDS round trip by the sparse-reset walk
+    constexpr int ROW = EUC ? 16 : 8;        // floats per beat and vector
+    constexpr int LPB = ROW / EPL;           // lanes per beat
+    constexpr int BPP = kThreads / LPB;      // beats per pass
+    constexpr int SUB = PASSES * BPP;        // beats per tile
+
+    __shared__ float s_sum0[SUB + kLook];
+    __shared__ float s_sum1[EUC ? 1 : SUB + kLook];
+    __shared__ uint32_t s_ctl[SUB + kLook];
+    __shared__ float s_out0[SUB + kLook];
+    __shared__ float s_out1[EUC ? 1 : SUB + kLook];
+
+    const int tid = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * SUB;
+    const uint64_t left = n - base;
+    const int cnt = (left < (uint64_t)SUB) ? (int)left : SUB;
+    const bool last_tile = (left <= (uint64_t)SUB);
+    const int part = tid % LPB;  // which EPL elements of the beat
+    unsigned long long *const header = args.chain;
+    unsigned long long *const slots = args.chain + 32;  // behind the 256-byte header, two words per tile
+
+    // phase 1: tree sums of the tile's beats
+    VT va[PASSES], vb[PASSES];
+    uint32_t vc[PASSES];
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+        const int bl = u * BPP + tid / LPB;
+        if (bl < cnt) {
+            const uint64_t e = (base + bl) * ROW + part * EPL;
+            va[u] = ld<VT, NT>(args.a + e);
+            vb[u] = ld<VT, NT>(args.b + e);
+            vc[u] = args.ctl[base + bl];
+        } else {
+            va[u] = (VT)(0.0f); vb[u] = (VT)(0.0f); vc[u] = 0u;
+        }
+    }
+    // does a pair enter this tile from the previous one?  (thread 0 only; the word arrives with the operands)
+    const uint32_t before = (tid == 0 && base != 0) ? args.ctl[base - 1] : 0x10000u;
+    bool any_reset = false;
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+        const int bl = u * BPP + tid / LPB;
+        const uint32_t mbits = vc[u] >> (part * EPL);
+        float s0[EPL], s1[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const bool on = (mbits >> j) & 1u;
+            if (EUC) {
+                const float d = on ? (va[u][j] - vb[u][j]) : 0.0f;  // :221-245
+                s0[j] = d * d;                                      // :399-419
+            } else {
+                const float q = on ? va[u][j] : 0.0f;               // :246-268
+                const float c = on ? vb[u][j] : 0.0f;
+                s0[j] = q * c;                                      // :420-453
+                s1[j] = c * c;
+            }
+        }
+        float r0, r1 = 0.0f;
+        if (EUC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s0[j] = s0[j] + quad_xor2(s0[j]);  // i, i+8
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s0[j] = s0[j] + quad_xor1(s0[j]);  // i, i+4
+            r0 = (s0[0] + s0[2]) + (s0[1] + s0[3]);                        // i, i+2 then 0, 1
+        } else if (EPL == 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s0[j] = s0[j] + quad_xor1(s0[j]); s1[j] = s1[j] + quad_xor1(s1[j]); }  // i, i+4
+            r0 = (s0[0] + s0[2]) + (s0[1] + s0[3]);
+            r1 = (s1[0] + s1[2]) + (s1[1] + s1[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { s0[j] = s0[j] + quad_xor2(s0[j]); s1[j] = s1[j] + quad_xor2(s1[j]); }  // i, i+4
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { s0[j] = s0[j] + quad_xor1(s0[j]); s1[j] = s1[j] + quad_xor1(s1[j]); }  // i, i+2
+            r0 = s0[0] + s0[1];                                                                                   // 0, 1
+            r1 = s1[0] + s1[1];
+        }
+        if (args.diag == 2) {  // diagnostic: what the loads and the tree sums alone cost
+            if (part == 0 && bl < cnt) {
+                st<float, NT>(args.out0 + base + bl, r0);
+                if (!EUC) st<float, NT>(args.out1 + base + bl, r1);
+            }
+            continue;
+        }
+        if (part == 0 && bl < cnt) {
+            s_sum0[bl] = r0;
+            if (!EUC) s_sum1[bl] = r1;
+            s_ctl[bl] = vc[u];
+            any_reset |= ((vc[u] >> 16) & 1u) != 0u;
+        }
+    }
+    if (args.diag == 2) return;
+    if (args.diag == 1) {  // diagnostic: no accumulation, the beat sums go out as they are
+        __syncthreads();
+        for (int t0 = tid; t0 < cnt; t0 += kThreads) {
+            st<float, NT>(args.out0 + base + t0, s_sum0[t0]);
+            if (!EUC) st<float, NT>(args.out1 + base + t0, s_sum1[t0]);
+        }
+        return;
+    }
+    // tiles with next to no pair end in them are walked by next to no lane: those fetch four beat sums per LDS round trip
+    const bool sparse = __syncthreads_count(any_reset ? 1 : 0) < 4;
+
+    // phase 2: one lane per vector pair accumulates its beats in order; the lane that reaches the end of the tile
+    // hands the running sums on (to the next tile, or to the context after the last tile)
+    auto hand_on = [&](float acc0, float acc1) {
+        if (last_tile) {
+            args.state_out[0] = canon_nan(acc0);
+            if (!EUC) args.state_out[1] = canon_nan(acc1);
+        } else {
+            __hip_atomic_store(slots + 2 * (uint64_t)blockIdx.x, chain_word(args.epoch, acc0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!EUC) __hip_atomic_store(slots + 2 * (uint64_t)blockIdx.x + 1, chain_word(args.epoch, acc1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto walk = [&](int i, float acc0, float acc1) {
+        if (!sparse) {
+            bool rs;
+            do {
+                acc0 = acc0 + s_sum0[i];
+                s_out0[i] = acc0;
+                rs = ((s_ctl[i] >> 16) & 1u) != 0u;
+                if (!EUC) {
+                    acc1 = acc1 + s_sum1[i];
+                    s_out1[i] = acc1;
+                }
+                ++i;
+            } while (i < cnt && !rs);
+            if (i == cnt) hand_on(rs ? 0.0f : acc0, rs ? 0.0f : acc1);
+        } else {
+            bool more = true;
+            while (more) {
+                float v0[kLook], v1[kLook];
+                uint32_t c[kLook];
+#pragma unroll
+                for (int k = 0; k < kLook; ++k) {
+                    v0[k] = s_sum0[i + k];
+                    if (!EUC) v1[k] = s_sum1[i + k];
+                    c[k] = s_ctl[i + k];
+                }
+#pragma unroll
+                for (int k = 0; k < kLook; ++k) {
+                    if (more) {
+                        const bool rs = ((c[k] >> 16) & 1u) != 0u;
+                        acc0 = acc0 + v0[k];
+                        s_out0[i + k] = acc0;
+                        if (!EUC) {
+                            acc1 = acc1 + v1[k];
+                            s_out1[i + k] = acc1;
+                        }
+                        const bool last = (i + k + 1 == cnt);
+                        if (last) hand_on(rs ? 0.0f : acc0, rs ? 0.0f : acc1);
+                        more = !rs && !last;
+                    }
+                }
+                i += kLook;
+            }
+        }
+    };
+    for (int t0 = tid; t0 < cnt; t0 += kThreads) {
+        if (t0 != 0 && (((s_ctl[t0 - 1] >> 16) & 1u) != 0u)) walk(t0, 0.0f, 0.0f);
+    }
+    if (tid == 0) {  // beat 0 of the tile: the stream's first beat, a fresh pair, or the pair that runs on from the previous tile
+        float acc0 = 0.0f, acc1 = 0.0f;
+        if (base == 0) {
+            acc0 = args.state_in[0];
+            if (!EUC) acc1 = args.state_in[1];
+        } else if (((before >> 16) & 1u) == 0u) {
+            acc0 = chain_wait(slots + 2 * (uint64_t)(blockIdx.x - 1), args.epoch, header);
+            if (!EUC) acc1 = chain_wait(slots + 2 * (uint64_t)(blockIdx.x - 1) + 1, args.epoch, header);
+        }
+        walk(0, acc0, acc1);
+    }
+    __syncthreads();
+
+    // phase 3: coalesced result store
+    for (int t0 = tid; t0 < cnt; t0 += kThreads) {
+        st<float, NT>(args.out0 + base + t0, canon_nan(s_out0[t0]));
+        if (!EUC) st<float, NT>(args.out1 + base + t0, canon_nan(s_out1[t0]));
+    }
+}
+
+size_t vec_chain_bytes(uint64_t n) { return 256 + ((n + 127) / 128) * 16; }
+
 // ------------------------------------------------------- ray pre-processing
 // The step in front of the datapath: the ray fields that the reference's software model
 // derives from (origin, dir) before a record is poked into the RTL (reference
@@ -576,7 +801,7 @@ static inline int min_align(const void *const *ptrs, int count) {
 // kernel at 2^24 ops runs at 0.765 of the HBM peak with the 7 workgroups per CU its registers allow, 0.82 with
 // 3).  A launch states how many 256-thread workgroups a CU may hold by asking for that share of the CU's 160 KiB
 // of LDS as dynamic shared memory, which the kernel never touches.
-constexpr int kBoxWgsPerCu = 3, kTriWgsPerCu = 5, kVecWgsPerCu = 99;  // from sweeps on MI355X
+constexpr int kBoxWgsPerCu = 3, kTriWgsPerCu = 5, kEucWgsPerCu = 4, kVecWgsPerCu = 99;  // from sweeps on MI355X
 
 static unsigned residency_lds_guess(int w, unsigned static_lds) {
     // gfx950 hands out LDS in granules of 1280 bytes, 128 of them per CU (measured: the plateaus of the
@@ -626,7 +851,7 @@ static Residency residency(const void *kernel, int slot, int wgs, int dflt, unsi
     return cache[slot][w];
 }
 
-enum { kSlotBox = 0, kSlotBoxDerive, kSlotTri, kSlotTriDerive, kSlotEuc, kSlotAng };
+enum { kSlotBox = 0, kSlotBoxDerive, kSlotTri, kSlotTriDerive, kSlotEuc, kSlotAng, kSlotEucChain, kSlotAngChain };
 
 static unsigned residency_lds(const void *kernel, int slot, int wgs, int dflt, unsigned static_lds) {
     return residency(kernel, slot, wgs, dflt, static_lds).lds;
@@ -736,8 +961,37 @@ template <bool EUC, bool NT> static void launch_vec_p(const VecArgs &args, uint6
     }
 }
 
+template <bool EUC, bool NT> static void launch_chain_p(const VecArgs &args, uint64_t n, int passes, unsigned lds, hipStream_t stream) {
+    const uint64_t sub = (uint64_t)passes * (kThreads / (EUC ? 4 : 2));
+    const unsigned blocks = (unsigned)((n + sub - 1) / sub);
+    switch (passes) {
+    case 2: hipLaunchKernelGGL((k_vec_chain<EUC, NT, 2, 4>), dim3(blocks), dim3(kThreads), lds, stream, args, n); break;
+    case 8: hipLaunchKernelGGL((k_vec_chain<EUC, NT, 8, 4>), dim3(blocks), dim3(kThreads), lds, stream, args, n); break;
+    default: hipLaunchKernelGGL((k_vec_chain<EUC, NT, 4, 4>), dim3(blocks), dim3(kThreads), lds, stream, args, n); break;
+    }
+}
+
 template <bool EUC> static hipError_t launch_vec(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream) {
     if (n == 0) return hipSuccess;
+    // Two shapes with identical results.  Chained: fixed tiles that hand their running sums on (needs the workspace).
+    // Owning: a workgroup owns whole vector pairs and searches for their boundaries.  Measured inside the benchmark
+    // process (scripts/bench_ctx.sh, 2^24 beats): Euclidean 0.814 chained against 0.800 owning, angular 0.745 chained
+    // against 0.762 owning, so each opcode defaults to its better shape.  Variant 23 (21, 22): owning for both; 27
+    // (24, 25): chained for both.
+    const bool chained = args.chain != nullptr && (t.variant == 27 || t.variant == 24 || t.variant == 25 || (EUC && !(t.variant >= 21 && t.variant <= 23)));
+    if (chained) {
+        VecArgs a2 = args;
+        a2.diag = (t.variant == 24) ? 1u : (t.variant == 25) ? 2u : 0u;
+        const int passes = (t.vec_passes == 2 || t.vec_passes == 4 || t.vec_passes == 8) ? t.vec_passes : (EUC ? 8 : 4);
+        if ((n + 127) / 128 > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        // residency: the Euclidean shape (64 KiB of loads in flight per workgroup) is best with 4 workgroups per CU (0.824
+        // of the HBM roof against 0.79 with the 6 its registers allow), the angular shape with all it can get
+        const unsigned lds = residency_lds(reinterpret_cast<const void *>(&k_vec_chain<EUC, true, EUC ? 8 : 4, 4>), EUC ? kSlotEucChain : kSlotAngChain, t.wgs_per_cu,
+                                           (EUC && passes == 8) ? kEucWgsPerCu : kVecWgsPerCu, 8192u + 64u);
+        if (use_nt(t)) launch_chain_p<EUC, true>(a2, n, passes, lds, stream);
+        else launch_chain_p<EUC, false>(a2, n, passes, lds, stream);
+        return hipGetLastError();
+    }
     // defaults from interleaved sweeps on MI355X: sub-tiles of 512 beats for both opcodes; the Euclidean shape (loads
     // issued from the nominal start) wants the nominal tile equal to the sub-tile, the angular shape (loads from the
     // first pair boundary) a tile a few beats shorter, so that the pair that hangs over the nominal end still fits

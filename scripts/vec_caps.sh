@@ -1,0 +1,11 @@
+OUT=gpurun_out/vec_caps.txt
+mkdir -p gpurun_out; : > $OUT
+one() { local label=$1; local w=$2; shift; shift
+  timeout -k 10 150 python bench.py --only $w --steps 200 --warmup 100 --no-cpu-baseline "$@" 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-44s kernel_ms %8.4f frac %.4f' % ('$label', r['per_opcode']['$w']['kernel_ms'], r['roofline']['frac']))" >> $OUT || { echo "FAILED $label" >> $OUT; exit 1; }
+}
+for w in angular euclid; do
+  for p in 4 8; do
+    for c in 3 4 5 6 7 8 10 99; do one "$w passes $p cap $c" $w --vec-passes $p --wgs-per-cu $c; done
+  done
+done
+cat $OUT

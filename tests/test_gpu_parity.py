@@ -146,11 +146,14 @@ def test_angular_pairs(ctx, oracle, torch_cuda, pairs, device):
     check_angular(ctx, oracle, q, c, ctl, device, torch_cuda)
 
 
+@pytest.mark.parametrize("variant", [0, 23, 27, 21, 22])
 @pytest.mark.parametrize("tile,passes", [(64, 2), (240, 4), (256, 2), (512, 0), (512, 8), (2048, 4)])
-def test_vec_tiles_and_long_pairs(ctx, oracle, torch_cuda, tile, passes):
+def test_vec_tiles_and_long_pairs(ctx, oracle, torch_cuda, tile, passes, variant):
     """Pairs longer than a sub-tile and longer than a whole tile; batch ends mid-pair;
-    batch starts with a carried-in register."""
-    ctx.set_tuning(vec_tile=tile, vec_passes=passes)
+    batch starts with a carried-in register.  Variant 0: each opcode in its default shape; 27: fixed tiles that hand
+    their running sums on, for both (the tile knob does not apply); 23 / 21 / 22: the shape in which a workgroup owns
+    whole pairs, for both, with its two walks."""
+    ctx.set_tuning(vec_tile=tile, vec_passes=passes, variant=variant)
     lengths = np.array([16 * 700, 5, 16 * 300 + 3, 1, 16 * 2100, 40, 16 * 256, 16 * 257, 9], np.int64)
     a, b, ctl, _ = gen.vec_beats(lengths.size, 16, seed=31, lengths=lengths)
     ctl = ctl.copy()
@@ -172,7 +175,8 @@ def test_vec_no_reset_anywhere(ctx, oracle, torch_cuda):
 
 @pytest.mark.parametrize("width", [16, 8])
 @pytest.mark.parametrize("pair_beats", [1 << 22, 1 << 18])
-def test_vec_reset_poor_streams_are_not_a_cliff(ctx, oracle, torch_cuda, width, pair_beats):
+@pytest.mark.parametrize("variant", [23, 27])
+def test_vec_reset_poor_streams_are_not_a_cliff(ctx, oracle, torch_cuda, width, pair_beats, variant):
     """2^22 beats with no reset at all (one endless pair) and with a reset every 2^18 beats: the workgroups whose
     nominal range holds no pair start must leave after looking at their own tile only (the accumulation itself is
     serial by definition and belongs to the workgroup in whose range the pair starts).  Bit-exact against the
@@ -196,6 +200,7 @@ def test_vec_reset_poor_streams_are_not_a_cliff(ctx, oracle, torch_cuda, width, 
         bt.set_euclid(da, db, dc, out0, nb)
     else:
         bt.set_angular(da, db, dc, out0, out1, nb)
+    ctx.set_option("variant", variant)
     ctx.set_accum([0.5, -2.0, 3.0])
     ctx.eval(bt)                                     # first call: code object load and the like
     ctx.set_accum([0.5, -2.0, 3.0])
@@ -213,7 +218,8 @@ def test_vec_reset_poor_streams_are_not_a_cliff(ctx, oracle, torch_cuda, width, 
         assert_bits_equal(out1.cpu().numpy(), wn, "angular_norm")
         assert_bits_equal(ctx.get_accum()[1:3], np.array([sd, sn], f32), "angular registers after the batch")
     assert wall < 1.0, "reset-poor stream took %.3f s" % wall
-    print("reset-poor stream, width %d, pair of %d beats: %.1f ms" % (width, pair_beats, wall * 1e3))
+    assert ctx.get_option("vec_chain_giveups") == 0
+    print("reset-poor stream, width %d, pair of %d beats, variant %d: %.1f ms" % (width, pair_beats, variant, wall * 1e3))
 
 
 def test_accumulators_run_across_batches(ctx, oracle, torch_cuda):
