@@ -198,6 +198,9 @@ int rt_dp_eval_ctx(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch 
  * NULL = the context's own non-blocking stream) and returns without
  * synchronising.  Ordering against the producers of the operands is the
  * caller's: launch on the stream that produced them, or synchronise first.
+ * Batches of one context execute in the order they were given (they share its
+ * accumulator registers and its workspace): a caller that launches batches of ONE
+ * context on different streams must order those streams itself.
  * The same holds for every entry point below that is described as
  * asynchronous (rt_dp_ray_prepare, rt_dp_knn_euclid16, rt_dp_knn_angular16,
  * rt_dp_knn_tree_euclid16); the synchronous ones wait for the whole device

@@ -110,8 +110,9 @@ ffac = sorted(fcal.values())[len(fcal) // 2] if fcal else 2.0
 wfac = sorted(wcal.values())[len(wcal) // 2] if wcal else 1.0
 lines.append("\nFETCH_SIZE correction used: x%.3f (KiB -> bytes: x1024, then the factor).  WRITE_SIZE correction: x%.3f.\n" % (ffac, wfac))
 
-UNITS = {"box": ("rtdp::k_box", 156, 136, 20), "tri": ("rtdp::k_tri", 76, 64, 12),
-         "euclid": ("rtdp::k_vec<true", 136, 132, 4), "angular": ("rtdp::k_vec<false", 76, 68, 8)}
+UNITS = {"box": (("rtdp::k_box",), 156, 136, 20), "tri": (("rtdp::k_tri",), 76, 64, 12),
+         "euclid": (("rtdp::k_vec<true", "rtdp::k_vec_chain<true"), 136, 132, 4),
+         "angular": (("rtdp::k_vec<false", "rtdp::k_vec_chain<false"), 76, 68, 8)}
 lines += ["## Datapath kernels (headline batch of each opcode)\n",
           "| opcode | kernel | units per launch | fetched B/unit (algorithmic) | written B/unit (algorithmic) | HBM B/unit (algorithmic) |\n|---|---|---|---|---|---|"]
 traffic = {}
