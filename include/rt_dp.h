@@ -535,7 +535,7 @@ int rt_dp_set_tuning(rt_dp_ctx *ctx, int ops_per_lane, int nontemporal, int vec_
  * pass (needs 16-byte aligned record arrays), 0 (default) picks 2 when the alignment allows. */
 int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value);
 /* Reads a knob back as the library resolved it: the keys above give the value in effect ("ops_per_lane",
- * "nontemporal" 0/1, "vec_tile" with the Euclidean default filled in: the angular default is 8 beats shorter), and "box_wgs_per_cu" / "tri_wgs_per_cu" give the
+ * "nontemporal" 0/1, "vec_tile" as requested or 512: it applies to the owning shape of the beat kernels only, whose angular default is 504), and "box_wgs_per_cu" / "tri_wgs_per_cu" give the
  * residency that box / triangle batches large enough for the cap run with, as the runtime's occupancy query
  * reports it for the launch configuration in use (0 = uncapped).  The cap is set through the amount of
  * dynamic LDS a launch asks for; the amount is verified against that query once per process, so a runtime

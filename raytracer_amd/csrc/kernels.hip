@@ -209,12 +209,15 @@ __global__ __launch_bounds__(256) void k_tri_derive(TriArgs args, uint64_t first
 //
 // The accumulator (:1133-1154, angular :1028-1064) is a strictly sequential
 // float sum over the beats of one vector pair, so it cannot be re-associated.
-// Each workgroup therefore owns whole vector pairs: its range starts at the
-// first pair boundary at or after blockIdx * tile and ends at the first pair
-// boundary at or after (blockIdx + 1) * tile.  Inside a sub-tile (PASSES x 64 or x 128 beats) the
-// per-beat tree sums go to LDS and one lane per vector pair walks its beats in
-// order.  A pair longer than a tile is handled entirely by the workgroup in
-// whose nominal range it starts.
+// Two kernel shapes respect that, with identical results:
+//   k_vec ("owning")        a workgroup owns whole vector pairs: its range starts at the first pair boundary at
+//                           or after blockIdx * tile and ends at the first pair boundary at or after
+//                           (blockIdx + 1) * tile; a pair longer than a tile is handled entirely by the
+//                           workgroup in whose nominal range it starts;
+//   k_vec_chain ("chained") fixed tiles; the pair that enters a tile from the previous one is continued from
+//                           the running sums the previous workgroup publishes (further down).
+// In both, inside a sub-tile (PASSES x 64 or x 128 beats) the per-beat tree sums go to LDS and one lane per
+// vector pair walks its beats in order.
 
 constexpr int kThreads = 256;  // threads per workgroup of the beat kernels
 
