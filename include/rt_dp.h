@@ -204,7 +204,13 @@ int rt_dp_eval_ctx(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch 
  * The same holds for every entry point below that is described as
  * asynchronous (rt_dp_ray_prepare, rt_dp_knn_euclid16, rt_dp_knn_angular16,
  * rt_dp_knn_tree_euclid16); the synchronous ones wait for the whole device
- * before they read their arguments.                                            */
+ * before they read their arguments.
+ * `hip_stream` may be a stream under capture (hipStreamBeginCapture): the batch
+ * then becomes kernel and 16-byte copy nodes of the caller's graph, nothing is
+ * allocated, and every replay evaluates whatever the same arrays hold by then.
+ * The accumulator registers carry from replay to replay and to and from batches
+ * launched directly, in the order the work executes; run one such batch directly
+ * before capturing, so that the one-time set-up of the kernels is not captured. */
 int rt_dp_launch(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *out, void *hip_stream);
 int rt_dp_synchronize(rt_dp_ctx *ctx);
 

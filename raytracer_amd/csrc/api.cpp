@@ -47,6 +47,7 @@ struct rt_dp_ctx {
     // accumulator registers live in HBM; two copies so that the workgroup that
     // reads the incoming value never races the one that writes the outgoing one
     float *d_state = nullptr;  // [3][4]: {euclid, dot, norm, pad}; copies 0 / 1 alternate, copy 2 is a call's backup
+    bool state_pinned = false;  // a captured graph holds the address of copy `cur`: the registers stay there from then on
     int cur = 0;               // which copy is current
     // grow-only staging for host-pointer batches
     char *d_stage = nullptr;
@@ -212,6 +213,21 @@ int chain_for(rt_dp_ctx *ctx, uint64_t n, hipStream_t s, VecArgs &a) {
     return RT_DP_OK;
 }
 
+bool is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cap != hipStreamCaptureStatusNone;
+}
+
+// The kernels of a batch read the registers from copy `cur` and left the new ones in the other copy: make that
+// the current one.  Normally the two copies just swap roles; once a graph has captured their addresses the new
+// values are copied back instead, so that replays and direct launches keep finding the registers in one place.
+int commit_state(rt_dp_ctx *ctx, hipStream_t s) {
+    if (!ctx->state_pinned) { ctx->cur ^= 1; return RT_DP_OK; }
+    HIP_TRY(hipMemcpyAsync(ctx->d_state + 4 * ctx->cur, ctx->d_state + 4 * (ctx->cur ^ 1), 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return RT_DP_OK;
+}
+
 // Enqueue the kernels of one batch whose arrays are all device pointers.
 int launch_device(rt_dp_ctx *ctx, const rt_dp_op_batch *in, const rt_dp_result_batch *out, hipStream_t s) {
     const uint64_t n_tri = in->n[RT_DP_OP_TRIANGLE], n_box = in->n[RT_DP_OP_QUADBOX];
@@ -238,22 +254,29 @@ int launch_device(rt_dp_ctx *ctx, const rt_dp_op_batch *in, const rt_dp_result_b
         return RT_DP_OK;
     }
     if (n_euc || n_ang) {  // (16-byte alignment of a / b: check_batch, before anything was enqueued)
+        // A batch that is being captured into a graph runs again later with the arguments of today: the hand-over
+        // words of the chained kernels are told apart by a per-launch number, which a replay would repeat, so the
+        // captured kernels are the ones that own whole pairs and need no workspace; and the registers stay at the
+        // address the graph holds.
+        const bool captured = is_capturing(s);
+        if (captured) ctx->state_pinned = true;
         float *cur = ctx->d_state + 4 * ctx->cur, *nxt = ctx->d_state + 4 * (ctx->cur ^ 1);
         // registers of an opcode without beats in this batch are carried over unchanged
         HIP_TRY(hipMemcpyAsync(nxt, cur, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (n_euc) {
             VecArgs a{in->euc.a, in->euc.b, in->euc.ctl, out->euc.accumulator, nullptr, cur + 0, nxt + 0};
-            int rc = chain_for(ctx, n_euc, s, a);
+            int rc = captured ? RT_DP_OK : chain_for(ctx, n_euc, s, a);
             if (rc != RT_DP_OK) return rc;
             HIP_TRY(launch_euclid(a, n_euc, ctx->tuning, s));
         }
         if (n_ang) {
             VecArgs a{in->ang.a, in->ang.b, in->ang.ctl, out->ang.dot_product, out->ang.norm, cur + 1, nxt + 1};
-            int rc = chain_for(ctx, n_ang, s, a);
+            int rc = captured ? RT_DP_OK : chain_for(ctx, n_ang, s, a);
             if (rc != RT_DP_OK) return rc;
             HIP_TRY(launch_angular(a, n_ang, ctx->tuning, s));
         }
-        ctx->cur ^= 1;
+        int rc = commit_state(ctx, s);
+        if (rc != RT_DP_OK) return rc;
     }
     return RT_DP_OK;
 }
@@ -484,9 +507,7 @@ int rt_dp_launch(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *o
     if (s != ctx->stream && beats) {
         // the registers were read and written on the caller's stream: remember where, unless the stream is being
         // captured into a graph (an event recorded there cannot be waited for from outside the graph)
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
-        if (cap == hipStreamCaptureStatusNone) {
+        if (!is_capturing(s)) {
             HIP_TRY(hipEventRecord(ctx->launched, s));
             ctx->launched_pending = true;
         }
@@ -613,7 +634,8 @@ int rt_dp_eval_bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt
                 // registers of an opcode without beats in this piece are carried over unchanged
                 HIP_TRY(hipMemcpyAsync(nxt, cur, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
                 HIP_TRY(stream_fused_fold(view, m, cur, nxt, out_words + off * 21, s));
-                ctx->cur ^= 1;
+                rc = commit_state(ctx, s);
+                if (rc != RT_DP_OK) return rc;
             }
         }
         uint32_t bad = 0;

@@ -121,3 +121,89 @@ def test_default_context_of_a_thread_is_released_when_the_thread_ends(torch_cuda
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, "24 short-lived threads cost %d MiB of device memory" % ((free0 - free1) >> 20)
+
+
+def test_a_batch_captured_into_a_graph_replays_with_new_operands_and_carries_the_registers(ctx, oracle, torch_cuda):
+    """rt_dp_launch on a stream under capture: the replays read whatever the operand arrays hold by then, and the
+    accumulator registers carry replay -> replay -> direct launch -> replay as they would over plain batches."""
+    torch = torch_cuda
+    n_box, n_beats = 3000, 4000
+    rounds = []
+    for seed in (81, 82, 83, 84):
+        fields = gen.box_ops(n_box, seed=seed)
+        a, b, ctl, _ = gen.vec_beats(1500, 16, seed=seed)
+        qa, qb, qctl, _ = gen.vec_beats(1500, 8, seed=seed + 100)
+        a, b, ctl = a[:n_beats], b[:n_beats], ctl[:n_beats].copy()      # a graph replays one fixed size
+        qa, qb, qctl = qa[:n_beats], qb[:n_beats], qctl[:n_beats].copy()
+        assert ctl.shape[0] == n_beats and qctl.shape[0] == n_beats
+        ctl[-1] &= u32(0xFFFF)                   # both streams end inside a pair: the registers are live afterwards
+        qctl[-1] &= u32(0xFFFF)
+        ctl[0] &= u32(0xFFFF)                    # ... and start inside one
+        qctl[0] &= u32(0xFFFF)
+        rounds.append((fields, a, b, ctl, qa, qb, qctl))
+
+    def dev(x):
+        return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+    d_fields = [dev(f) for f in rounds[0][0]]
+    d_a, d_b, d_ctl = dev(rounds[0][1]), dev(rounds[0][2]), dev(rounds[0][3].view(np.int32))
+    d_qa, d_qb, d_qctl = dev(rounds[0][4]), dev(rounds[0][5]), dev(rounds[0][6].view(np.int32))
+    tmin = [torch.empty(n_box, dtype=torch.float32, device="cuda") for _ in range(4)]
+    flags = torch.empty(n_box, dtype=torch.int32, device="cuda")
+    acc = torch.empty(n_beats, dtype=torch.float32, device="cuda")
+    dot, norm = torch.empty(n_beats, dtype=torch.float32, device="cuda"), torch.empty(n_beats, dtype=torch.float32, device="cuda")
+    bt = capi.Batch()
+    bt.set_box(d_fields, tmin, flags)
+    bt.set_euclid(d_a, d_b, d_ctl, acc)
+    bt.set_angular(d_qa, d_qb, d_qctl, dot, norm)
+    bt.finalize()
+
+    def load(r):
+        fields, a, b, ctl, qa, qb, qctl = rounds[r]
+        for d, f in zip(d_fields, fields):
+            d.copy_(dev(f))
+        d_a.copy_(dev(a)); d_b.copy_(dev(b)); d_ctl.copy_(dev(ctl.view(np.int32)))
+        d_qa.copy_(dev(qa)); d_qb.copy_(dev(qb)); d_qctl.copy_(dev(qctl.view(np.int32)))
+        torch.cuda.synchronize()
+
+    state = [f32(0), f32(0), f32(0)]
+
+    def check(r, what):
+        fields, a, b, ctl, qa, qb, qctl = rounds[r]
+        want_t, want_f = oracle.box_soa(fields)
+        want_acc, state[0] = oracle.euclid_beats(a, b, ctl, state[0])
+        want_dot, want_norm, state[1], state[2] = oracle.angular_beats(qa, qb, qctl, state[1], state[2])
+        assert_bits_equal(acc.cpu().numpy(), want_acc, what + ": euclidean beats")
+        assert_bits_equal(dot.cpu().numpy(), want_dot, what + ": angular dot")
+        assert_bits_equal(norm.cpu().numpy(), want_norm, what + ": angular norm")
+        assert_bits_equal(flags.cpu().numpy().view(u32), want_f, what + ": box flags")
+        for k in range(4):
+            assert_bits_equal(tmin[k].cpu().numpy(), want_t[k], what + ": box tmin %d" % k)
+
+    stream = torch.cuda.Stream()
+    ctx.reset()
+    ctx.launch(bt, stream.cuda_stream)           # direct, also the kernels' one-time set-up
+    stream.synchronize()
+    check(0, "direct launch before the capture")
+
+    graph = torch.cuda.CUDAGraph()
+    load(1)
+    with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+        ctx.launch(bt, torch.cuda.current_stream().cuda_stream)
+    graph.replay()
+    torch.cuda.synchronize()
+    check(1, "first replay")
+    load(2)
+    graph.replay()
+    torch.cuda.synchronize()
+    check(2, "second replay, new operands")
+    load(3)
+    ctx.launch(bt, stream.cuda_stream)           # a direct launch between replays
+    stream.synchronize()
+    check(3, "direct launch between replays")
+    got = ctx.get_accum()
+    assert_bits_equal(got, np.array(state, f32), "registers after the direct launch")
+    load(0)
+    graph.replay()
+    torch.cuda.synchronize()
+    check(0, "replay after a direct launch")
