@@ -18,6 +18,15 @@ LIB_PATH = os.environ.get("RT_DP_LIB") or os.path.join(_HERE, "lib", "librt_dp.s
 OP_TRIANGLE, OP_QUADBOX, OP_EUCLIDEAN, OP_ANGULAR = 0, 1, 2, 3
 F_DEVICE_PTRS = 0x1
 F_DERIVE_RAY = 0x2
+F_BOX_TILED = 0x4
+F_TRI_TILED = 0x8
+TILE_OPS = 8192
+BOX_TILE_IN_WORDS, BOX_TILE_OUT_WORDS, TRI_TILE_IN_WORDS, TRI_TILE_OUT_WORDS = 34, 5, 16, 3
+
+
+def tiled_words(n, words):
+    """RT_DP_TILED_WORDS: 32-bit words of a tiled buffer of n ops with `words` words per op."""
+    return ((int(n) + TILE_OPS - 1) // TILE_OPS) * TILE_OPS * int(words)
 
 OK, EINVAL, ENULL, EOPCODE, EHIP, ENODEV, EALIGN, ENOMEM = 0, -1, -2, -3, -4, -5, -6, -7
 
@@ -123,7 +132,7 @@ class KnnTree(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_leaves", C.c_uint32), ("leaf_size", C.c_uint32), ("reserved", C.c_uint32),
                 ("points", C.c_void_p), ("index", C.c_void_p), ("leaf_lo", C.c_void_p), ("leaf_hi", C.c_void_p)]
 
-EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize",
+EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize", "rt_dp_tile_pack", "rt_dp_tile_unpack",
            "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_get_option", "rt_dp_knn_euclid16", "rt_dp_knn_angular16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_box_compact", "rt_dp_box_compact_static", "rt_dp_beat_offsets_host", "rt_dp_pairs_to_beats", "rt_dp_beats_to_pairs", "rt_dp_bvh4_build_device", "rt_dp_knn_tree_build_device", "rt_dp_knn_home_leaf", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
            "rt_dp_knn_tree_leaves", "rt_dp_knn_tree_build_host", "rt_dp_knn_home_leaf_host", "rt_dp_bvh4_max_nodes", "rt_dp_bvh4_build_host",
            "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
@@ -155,6 +164,8 @@ def load():
     L.rt_dp_eval_ctx.argtypes = [vp, C.POINTER(OpBatch), C.POINTER(ResultBatch)]
     L.rt_dp_launch.argtypes = [vp, C.POINTER(OpBatch), C.POINTER(ResultBatch), vp]
     L.rt_dp_synchronize.argtypes = [vp]
+    L.rt_dp_tile_pack.argtypes = [vp, C.POINTER(vp), C.c_uint32, C.c_uint64, vp, vp]
+    L.rt_dp_tile_unpack.argtypes = [vp, vp, C.POINTER(vp), C.c_uint32, C.c_uint64, vp]
     L.rt_dp_reset.argtypes = [vp]
     L.rt_dp_get_accum.argtypes = [vp, C.POINTER(C.c_float * 3)]
     L.rt_dp_set_accum.argtypes = [vp, C.POINTER(C.c_float * 3)]
@@ -230,6 +241,7 @@ class Batch:
         self._keep = []
         self._kinds = set()
         self._derive = False
+        self._tiled = 0
 
     def _p(self, x):
         self._keep.append(x)
@@ -271,6 +283,24 @@ class Batch:
         self.rb.tri.hit = self._p(hit)
         self.ob.n[OP_TRIANGLE] = int(fields[0].shape[0]) if n is None else int(n)
 
+    def set_box_tiled(self, operands, results, n):
+        """RT_DP_F_BOX_TILED: operands / results are CUDA tensors of tiled_words(n, 34) / tiled_words(n, 5) 32-bit words."""
+        assert operands.numel() >= tiled_words(n, BOX_TILE_IN_WORDS) and results.numel() >= tiled_words(n, BOX_TILE_OUT_WORDS)
+        assert operands.element_size() == 4 and results.element_size() == 4
+        self.ob.box.org[0] = self._p(operands)
+        self.rb.box.tmin_out[0] = self._p(results)
+        self.ob.n[OP_QUADBOX] = int(n)
+        self._tiled |= F_BOX_TILED
+
+    def set_tri_tiled(self, operands, results, n):
+        """RT_DP_F_TRI_TILED: operands / results are CUDA tensors of tiled_words(n, 16) / tiled_words(n, 3) 32-bit words."""
+        assert operands.numel() >= tiled_words(n, TRI_TILE_IN_WORDS) and results.numel() >= tiled_words(n, TRI_TILE_OUT_WORDS)
+        assert operands.element_size() == 4 and results.element_size() == 4
+        self.ob.tri.org[0] = self._p(operands)
+        self.rb.tri.t_num = self._p(results)
+        self.ob.n[OP_TRIANGLE] = int(n)
+        self._tiled |= F_TRI_TILED
+
     def set_euclid(self, a, b, ctl, acc, n=None):
         self.ob.euc.a, self.ob.euc.b, self.ob.euc.ctl = self._p(a), self._p(b), self._p(ctl)
         self.rb.euc.accumulator = self._p(acc)
@@ -285,7 +315,7 @@ class Batch:
     def finalize(self):
         if len(self._kinds) > 1:
             raise ValueError("a batch must not mix host and device arrays")
-        self.ob.flags = (F_DEVICE_PTRS if "cuda" in self._kinds else 0) | (F_DERIVE_RAY if self._derive else 0)
+        self.ob.flags = (F_DEVICE_PTRS if "cuda" in self._kinds else 0) | (F_DERIVE_RAY if self._derive else 0) | self._tiled
         return self
 
     def derive_ray(self, on=True):
@@ -334,6 +364,29 @@ class Context:
 
     def synchronize(self):
         _check(self._L.rt_dp_synchronize(self._h))
+
+    def tile_pack(self, arrays, tiled, n=None, stream=None):
+        """arrays: CUDA tensors of n 32-bit elements each; tiled: CUDA tensor of tiled_words(n, len(arrays)) words."""
+        n = int(arrays[0].shape[0]) if n is None else int(n)
+        keep = set()
+        ptrs = (C.c_void_p * len(arrays))(*[_ptr(a, keep) for a in arrays])
+        tp = _ptr(tiled, keep)
+        if keep != {"cuda"}:
+            raise ValueError("tile_pack needs CUDA tensors")
+        assert all(a.element_size() == 4 and a.numel() >= n for a in arrays) and tiled.element_size() == 4
+        assert tiled.numel() >= tiled_words(n, len(arrays))
+        _check(self._L.rt_dp_tile_pack(self._h, ptrs, len(arrays), n, tp, C.c_void_p(stream) if stream else None))
+
+    def tile_unpack(self, tiled, arrays, n=None, stream=None):
+        n = int(arrays[0].shape[0]) if n is None else int(n)
+        keep = set()
+        ptrs = (C.c_void_p * len(arrays))(*[_ptr(a, keep) for a in arrays])
+        tp = _ptr(tiled, keep)
+        if keep != {"cuda"}:
+            raise ValueError("tile_unpack needs CUDA tensors")
+        assert all(a.element_size() == 4 and a.numel() >= n for a in arrays) and tiled.element_size() == 4
+        assert tiled.numel() >= tiled_words(n, len(arrays))
+        _check(self._L.rt_dp_tile_unpack(self._h, tp, ptrs, len(arrays), n, C.c_void_p(stream) if stream else None))
 
     def reset(self):
         _check(self._L.rt_dp_reset(self._h))

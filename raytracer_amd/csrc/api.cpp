@@ -111,7 +111,12 @@ int check_batch(const rt_dp_op_batch *in, const rt_dp_result_batch *out) {
     } while (0)
 
     const bool derive = (in->flags & RT_DP_F_DERIVE_RAY) != 0;
-    if (in->n[RT_DP_OP_TRIANGLE]) {
+    if ((in->flags & (RT_DP_F_BOX_TILED | RT_DP_F_TRI_TILED)) && !(in->flags & RT_DP_F_DEVICE_PTRS))
+        return fail(RT_DP_EINVAL, "tiled segments need device pointers (RT_DP_F_DEVICE_PTRS)");
+    if (in->n[RT_DP_OP_TRIANGLE] && (in->flags & RT_DP_F_TRI_TILED)) {
+        NEED(in->tri.org[0], "tri.org[0] (the tiled operand buffer)");
+        NEED(out->tri.t_num, "result tri.t_num (the tiled result buffer)");
+    } else if (in->n[RT_DP_OP_TRIANGLE]) {
         for (int a = 0; a < 3; ++a) {
             NEED(in->tri.org[a], "tri.org[]");
             if (derive) NEED(in->tri.dir[a], "tri.dir[]");
@@ -124,7 +129,10 @@ int check_batch(const rt_dp_op_batch *in, const rt_dp_result_batch *out) {
         NEED(out->tri.t_denom, "result tri.t_denom");
         NEED(out->tri.hit, "result tri.hit");
     }
-    if (in->n[RT_DP_OP_QUADBOX]) {
+    if (in->n[RT_DP_OP_QUADBOX] && (in->flags & RT_DP_F_BOX_TILED)) {
+        NEED(in->box.org[0], "box.org[0] (the tiled operand buffer)");
+        NEED(out->box.tmin_out[0], "result box.tmin_out[0] (the tiled result buffer)");
+    } else if (in->n[RT_DP_OP_QUADBOX]) {
         for (int a = 0; a < 3; ++a) {
             NEED(in->box.org[a], "box.org[]");
             NEED(in->box.dir[a], "box.dir[]");
@@ -233,12 +241,16 @@ int launch_device(rt_dp_ctx *ctx, const rt_dp_op_batch *in, const rt_dp_result_b
     const uint64_t n_tri = in->n[RT_DP_OP_TRIANGLE], n_box = in->n[RT_DP_OP_QUADBOX];
     const uint64_t n_euc = in->n[RT_DP_OP_EUCLIDEAN], n_ang = in->n[RT_DP_OP_ANGULAR];
     const bool derive = (in->flags & RT_DP_F_DERIVE_RAY) != 0;
-    if (n_box) {
+    if (n_box && (in->flags & RT_DP_F_BOX_TILED)) {
+        HIP_TRY(launch_box_tiled(in->box.org[0], reinterpret_cast<uint32_t *>(out->box.tmin_out[0]), n_box, ctx->tuning, s, derive));
+    } else if (n_box) {
         BoxArgs a;
         fill_box(a, in->box, out->box, derive);
         HIP_TRY(launch_box(a, n_box, ctx->tuning, s, derive));
     }
-    if (n_tri) {
+    if (n_tri && (in->flags & RT_DP_F_TRI_TILED)) {
+        HIP_TRY(launch_tri_tiled(in->tri.org[0], reinterpret_cast<uint32_t *>(out->tri.t_num), n_tri, ctx->tuning, s, derive));
+    } else if (n_tri) {
         TriArgs a;
         fill_tri(a, in->tri, out->tri, derive);
         HIP_TRY(launch_tri(a, n_tri, ctx->tuning, s, derive));
@@ -512,6 +524,42 @@ int rt_dp_launch(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *o
             ctx->launched_pending = true;
         }
     }
+    return RT_DP_OK;
+}
+
+static int tile_args(const char *who, rt_dp_ctx *ctx, const void *const *arrays, uint32_t n_arrays, uint64_t n, const void *tiled, TileList &l) {
+    if (!ctx) return fail(RT_DP_ENULL, "%s: ctx is NULL", who);
+    if (n_arrays < 1 || n_arrays > (uint32_t)kTileMaxArrays) return fail(RT_DP_EINVAL, "%s: n_arrays must be 1..%d", who, kTileMaxArrays);
+    if (n > kMaxOps) return fail(RT_DP_EINVAL, "%s: n = %llu is not representable (limit 2^40)", who, (unsigned long long)n);
+    if (n == 0) return RT_DP_OK;
+    if (!arrays || !tiled) return fail(RT_DP_ENULL, "%s: NULL argument", who);
+    if (reinterpret_cast<uintptr_t>(tiled) & 3u) return fail(RT_DP_EALIGN, "%s: the tiled buffer is not 4-byte aligned", who);
+    for (uint32_t k = 0; k < n_arrays; ++k) {
+        if (!arrays[k]) return fail(RT_DP_ENULL, "%s: arrays[%u] is NULL", who, k);
+        if (reinterpret_cast<uintptr_t>(arrays[k]) & 3u) return fail(RT_DP_EALIGN, "%s: arrays[%u] is not 4-byte aligned", who, k);
+        l.a[k] = static_cast<uint32_t *>(const_cast<void *>(arrays[k]));
+    }
+    for (uint32_t k = n_arrays; k < (uint32_t)kTileMaxArrays; ++k) l.a[k] = nullptr;
+    return RT_DP_OK;
+}
+
+int rt_dp_tile_pack(rt_dp_ctx *ctx, const void *const *arrays, uint32_t n_arrays, uint64_t n, void *tiled, void *hip_stream) {
+    TileList l;
+    int rc = tile_args("rt_dp_tile_pack", ctx, arrays, n_arrays, n, tiled, l);
+    if (rc != RT_DP_OK || n == 0) return rc;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
+    HIP_TRY(launch_tile_pack(l, (int)n_arrays, n, static_cast<uint32_t *>(tiled), hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
+    return RT_DP_OK;
+}
+
+int rt_dp_tile_unpack(rt_dp_ctx *ctx, const void *tiled, void *const *arrays, uint32_t n_arrays, uint64_t n, void *hip_stream) {
+    TileList l;
+    int rc = tile_args("rt_dp_tile_unpack", ctx, arrays, n_arrays, n, tiled, l);
+    if (rc != RT_DP_OK || n == 0) return rc;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
+    HIP_TRY(launch_tile_unpack(static_cast<const uint32_t *>(tiled), (int)n_arrays, n, l, hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
     return RT_DP_OK;
 }
 

@@ -9,6 +9,15 @@ namespace rtdp {
 constexpr int kBoxFields = 34;  // org xyz, dir xyz, inv xyz, extent, 4 x (x_min,y_min,z_min,x_max,y_max,z_max)
 constexpr int kTriFields = 15;  // org xyz, shear xyz, A xyz, B xyz, C xyz
 
+// Tiled layout of box / triangle batches: [tile][word][kTileOps], whole tiles (rt_dp.h: RT_DP_TILE_OPS and the
+// RT_DP_*_TILE_*_WORDS counts).
+constexpr uint32_t kTileOps = 8192;
+constexpr int kBoxOutWords = 5;   // tmin_out[0..3], flags
+constexpr int kTriInWords = 16;   // the 15 operands, then the packed axis selectors
+constexpr int kTriOutWords = 3;   // t_num, t_denom, hit
+constexpr int kTileMaxArrays = 40;
+struct TileList { uint32_t *a[kTileMaxArrays]; };
+
 struct BoxArgs {
     const float *in[kBoxFields];
     float *tmin[4];
@@ -64,6 +73,10 @@ struct Tuning {
 
 hipError_t launch_box(const BoxArgs &args, uint64_t n, const Tuning &t, hipStream_t stream, bool derive = false);  // derive: in[6..8] unused
 hipError_t launch_tri(const TriArgs &args, uint64_t n, const Tuning &t, hipStream_t stream, bool derive = false);  // derive: in[3..5] = dir, k unused
+hipError_t launch_box_tiled(const float *in, uint32_t *out, uint64_t n, const Tuning &t, hipStream_t stream, bool derive);
+hipError_t launch_tri_tiled(const float *in, uint32_t *out, uint64_t n, const Tuning &t, hipStream_t stream, bool derive);
+hipError_t launch_tile_pack(const TileList &arrays, int count, uint64_t n, uint32_t *tiled, hipStream_t stream);    // arrays are only read
+hipError_t launch_tile_unpack(const uint32_t *tiled, int count, uint64_t n, const TileList &arrays, hipStream_t stream);
 hipError_t launch_euclid(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
 int resolved_residency(const Tuning &t, bool box);  // workgroups per CU that large box / triangle batches run with (0: no cap), per the occupancy query
 hipError_t launch_angular(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);

@@ -109,6 +109,35 @@ __global__ __launch_bounds__(256) void k_box_derive(BoxArgs args, uint64_t first
     box_eval_store<V, NT>(args, i0, x);
 }
 
+// Tiled operand layout: [tile][field][kTileOps] with whole tiles, i.e. every field of kTileOps consecutive ops is one
+// contiguous 32 KiB run and a tile's runs follow each other.  The plain layout streams 39 arrays in lockstep, whose
+// mutual spacing (a caller's choice) decides how often their cache lines contend for one channel; here the spacing
+// is fixed by the layout.  Measured on MI355X against tile size: 64 .. 256 ops per tile are slower than the plain
+// layout (too short a run per DRAM page visit), 2048 .. 16384 are faster at every batch size, 8192 is the best.
+template <bool NT, bool DERIVE>
+__global__ __launch_bounds__(256) void k_box_tiled(const float *__restrict__ in, uint32_t *__restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t tile = i / kTileOps;
+    const uint32_t w = (uint32_t)(i % kTileOps);
+    const float *p = in + tile * (uint64_t)(kBoxFields * kTileOps) + w;
+    float x[kBoxFields];
+#pragma unroll
+    for (int f = 0; f < kBoxFields; ++f)
+        if (!DERIVE || f < 6 || f > 8) x[f] = ld<float, NT>(p + (size_t)f * kTileOps);
+    if (DERIVE) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[6 + c] = canon_nan(1.0f / x[3 + c]);
+    }
+    float t[4];
+    uint32_t fl;
+    box_one(x, t, fl);
+    uint32_t *q = out + tile * (uint64_t)(kBoxOutWords * kTileOps) + w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st<uint32_t, NT>(q + (size_t)k * kTileOps, __float_as_uint(t[k]));
+    st<uint32_t, NT>(q + (size_t)4 * kTileOps, fl);
+}
+
 // Diagnostic shape for bandwidth accounting (variant 10, never selected by default): the
 // box kernel's loads and stores with a trivial reduction in place of the datapath
 // arithmetic, i.e. what the memory pattern alone costs.  Its outputs are meaningless.
@@ -170,6 +199,51 @@ __global__ __launch_bounds__(256) void k_tri(TriArgs args, uint64_t first, uint6
     typename Pack<V>::U kk;
     tri_load<V, NT>(args, i0, x, kk);
     tri_eval_store<V, NT>(args, i0, x, kk);
+}
+
+// The triangle op over the tiled layout: 16 words in per op (15 operands and the packed selectors), 3 words out.
+template <bool NT, bool DERIVE>
+__global__ __launch_bounds__(256) void k_tri_tiled(const float *__restrict__ in, uint32_t *__restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t tile = i / kTileOps;
+    const uint32_t w = (uint32_t)(i % kTileOps);
+    const float *p = in + tile * (uint64_t)(kTriInWords * kTileOps) + w;
+    float x[kTriFields];
+#pragma unroll
+    for (int f = 0; f < kTriFields; ++f) x[f] = ld<float, NT>(p + (size_t)f * kTileOps);
+    uint32_t kk;
+    if (DERIVE) {
+        const float d[3] = {x[3], x[4], x[5]};
+        float inv[3], sh[3];
+        ray_derive(d, inv, kk, sh);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[3 + c] = sh[c];
+    } else {
+        kk = ld<uint32_t, NT>(p + (size_t)kTriFields * kTileOps);
+    }
+    float tn, td;
+    uint32_t h;
+    tri_one(x, kk, tn, td, h);
+    uint32_t *q = out + tile * (uint64_t)(kTriOutWords * kTileOps) + w;
+    st<uint32_t, NT>(q, __float_as_uint(tn));
+    st<uint32_t, NT>(q + (size_t)kTileOps, __float_as_uint(td));
+    st<uint32_t, NT>(q + (size_t)2 * kTileOps, h);
+}
+
+// Plain arrays <-> tiled buffer, any number of 32-bit arrays up to kTileMaxArrays.
+__global__ __launch_bounds__(256) void k_tile_pack(TileList l, int count, uint64_t n, uint32_t *__restrict__ tiled) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t *q = tiled + (i / kTileOps) * (uint64_t)count * kTileOps + (i % kTileOps);
+    for (int f = 0; f < count; ++f) q[(size_t)f * kTileOps] = l.a[f][i];
+}
+
+__global__ __launch_bounds__(256) void k_tile_unpack(const uint32_t *__restrict__ tiled, int count, uint64_t n, TileList l) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *q = tiled + (i / kTileOps) * (uint64_t)count * kTileOps + (i % kTileOps);
+    for (int f = 0; f < count; ++f) l.a[f][i] = q[(size_t)f * kTileOps];
 }
 
 // The same with shear and the axis selectors derived in the kernel from the ray direction, which then
@@ -805,6 +879,10 @@ static inline int min_align(const void *const *ptrs, int count) {
 // 3).  A launch states how many 256-thread workgroups a CU may hold by asking for that share of the CU's 160 KiB
 // of LDS as dynamic shared memory, which the kernel never touches.
 constexpr int kBoxWgsPerCu = 3, kTriWgsPerCu = 5, kEucWgsPerCu = 4, kVecWgsPerCu = 99;  // from sweeps on MI355X
+constexpr int kTiledWgsPerCu = 3;  // box and triangle kernels over the tiled layout
+
+enum { kSlotBox = 0, kSlotBoxDerive, kSlotTri, kSlotTriDerive, kSlotEuc, kSlotAng, kSlotEucChain, kSlotAngChain,
+       kSlotBoxTiled, kSlotBoxTiledDerive, kSlotTriTiled, kSlotTriTiledDerive, kSlots };
 
 static unsigned residency_lds_guess(int w, unsigned static_lds) {
     // gfx950 hands out LDS in granules of 1280 bytes, 128 of them per CU (measured: the plateaus of the
@@ -844,8 +922,8 @@ static Residency residency(const void *kernel, int slot, int wgs, int dflt, unsi
     if (w < 3) w = 3;
     // one entry per (kernel slot, residency); filled on first use, read-mostly afterwards
     static std::mutex lock;
-    static Residency cache[8][17];
-    static bool known[8][17];
+    static Residency cache[kSlots][17];
+    static bool known[kSlots][17];
     std::lock_guard<std::mutex> hold(lock);
     if (!known[slot][w]) {
         cache[slot][w] = resolve_residency(kernel, w, static_lds);
@@ -854,7 +932,7 @@ static Residency residency(const void *kernel, int slot, int wgs, int dflt, unsi
     return cache[slot][w];
 }
 
-enum { kSlotBox = 0, kSlotBoxDerive, kSlotTri, kSlotTriDerive, kSlotEuc, kSlotAng, kSlotEucChain, kSlotAngChain };
+
 
 static unsigned residency_lds(const void *kernel, int slot, int wgs, int dflt, unsigned static_lds) {
     return residency(kernel, slot, wgs, dflt, static_lds).lds;
@@ -933,6 +1011,56 @@ hipError_t launch_box(const BoxArgs &args, uint64_t n, const Tuning &t, hipStrea
         else launch_box_derive_v<false>(args, 0, n, v, lds, stream);
     } else if (use_nt(t)) launch_box_v<true>(args, 0, n, v, lds, stream);
     else launch_box_v<false>(args, 0, n, v, lds, stream);
+    return hipGetLastError();
+}
+
+static bool grid_fits(uint64_t n) { return (n + 255) / 256 <= 0x7FFFFFFFull; }
+
+hipError_t launch_box_tiled(const float *in, uint32_t *out, uint64_t n, const Tuning &t, hipStream_t stream, bool derive) {
+    if (n == 0) return hipSuccess;
+    if (!grid_fits(n)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    const int dflt = n >= (uint64_t(1) << 20) ? kTiledWgsPerCu : 99;
+    if (derive) {
+        const unsigned lds = residency_lds(reinterpret_cast<const void *>(&k_box_tiled<true, true>), kSlotBoxTiledDerive, t.wgs_per_cu, dflt, 0u);
+        if (use_nt(t)) hipLaunchKernelGGL((k_box_tiled<true, true>), grid, block, lds, stream, in, out, n);
+        else hipLaunchKernelGGL((k_box_tiled<false, true>), grid, block, lds, stream, in, out, n);
+    } else {
+        const unsigned lds = residency_lds(reinterpret_cast<const void *>(&k_box_tiled<true, false>), kSlotBoxTiled, t.wgs_per_cu, dflt, 0u);
+        if (use_nt(t)) hipLaunchKernelGGL((k_box_tiled<true, false>), grid, block, lds, stream, in, out, n);
+        else hipLaunchKernelGGL((k_box_tiled<false, false>), grid, block, lds, stream, in, out, n);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_tri_tiled(const float *in, uint32_t *out, uint64_t n, const Tuning &t, hipStream_t stream, bool derive) {
+    if (n == 0) return hipSuccess;
+    if (!grid_fits(n)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    const int dflt = n >= (uint64_t(1) << 20) ? kTiledWgsPerCu : 99;
+    if (derive) {
+        const unsigned lds = residency_lds(reinterpret_cast<const void *>(&k_tri_tiled<true, true>), kSlotTriTiledDerive, t.wgs_per_cu, dflt, 0u);
+        if (use_nt(t)) hipLaunchKernelGGL((k_tri_tiled<true, true>), grid, block, lds, stream, in, out, n);
+        else hipLaunchKernelGGL((k_tri_tiled<false, true>), grid, block, lds, stream, in, out, n);
+    } else {
+        const unsigned lds = residency_lds(reinterpret_cast<const void *>(&k_tri_tiled<true, false>), kSlotTriTiled, t.wgs_per_cu, dflt, 0u);
+        if (use_nt(t)) hipLaunchKernelGGL((k_tri_tiled<true, false>), grid, block, lds, stream, in, out, n);
+        else hipLaunchKernelGGL((k_tri_tiled<false, false>), grid, block, lds, stream, in, out, n);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_pack(const TileList &arrays, int count, uint64_t n, uint32_t *tiled, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    if (count < 1 || count > kTileMaxArrays || !grid_fits(n)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_tile_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, arrays, count, n, tiled);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_unpack(const uint32_t *tiled, int count, uint64_t n, const TileList &arrays, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    if (count < 1 || count > kTileMaxArrays || !grid_fits(n)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_tile_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tiled, count, n, arrays);
     return hipGetLastError();
 }
 

@@ -1,0 +1,158 @@
+// Throw-away measurement: the Quadbox kernel over a tiled operand layout ([tile][34 fields][T ops] floats in,
+// [tile][5][T] words out) against the plain 39-array layout, same arithmetic (box_one), same residency caps.
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I raytracer_amd/csrc -I include scripts/probe/tiled_probe.hip -o gpurun_out/tiled_probe
+#include "ops.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#pragma clang fp contract(off)
+using namespace rtdp;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <int T, int V>
+__global__ __launch_bounds__(256) void k_tiled(const float *__restrict__ in, uint32_t *__restrict__ out, uint64_t n) {
+    // T ops per tile; a workgroup covers 256*V consecutive ops = 256*V/T tiles (T <= 256*V) or a part of one
+    const uint64_t i = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * V;
+    if (i >= n) return;
+    const uint64_t tile = i / T, w = i % T;
+    const float *p = in + tile * (uint64_t)(kBoxFields * T) + w;
+    typedef float FV __attribute__((ext_vector_type(V)));
+    typedef uint32_t UV __attribute__((ext_vector_type(V)));
+    FV x[kBoxFields];
+#pragma unroll
+    for (int f = 0; f < kBoxFields; ++f) x[f] = __builtin_nontemporal_load(reinterpret_cast<const FV *>(p + f * T));
+    FV to[4]; UV fo;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        float r[kBoxFields], t[4]; uint32_t fl;
+#pragma unroll
+        for (int f = 0; f < kBoxFields; ++f) r[f] = x[f][v];
+        box_one(r, t, fl);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) to[k][v] = t[k];
+        fo[v] = fl;
+    }
+    uint32_t *q = out + tile * (uint64_t)(5 * T) + w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(to[k], reinterpret_cast<FV *>(q + k * T));
+    __builtin_nontemporal_store(fo, reinterpret_cast<UV *>(q + 4 * T));
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void k_tiled1(const float *__restrict__ in, uint32_t *__restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t tile = i / T, w = i % T;
+    const float *p = in + tile * (uint64_t)(kBoxFields * T) + w;
+    float x[kBoxFields];
+#pragma unroll
+    for (int f = 0; f < kBoxFields; ++f) x[f] = __builtin_nontemporal_load(p + f * T);
+    float t[4]; uint32_t fl;
+    box_one(x, t, fl);
+    uint32_t *q = out + tile * (uint64_t)(5 * T) + w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(__float_as_uint(t[k]), q + k * T);
+    __builtin_nontemporal_store(fl, q + 4 * T);
+}
+
+struct Ptrs { const float *in[kBoxFields]; uint32_t *out[5]; };
+__global__ __launch_bounds__(256) void k_plain(Ptrs a, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float x[kBoxFields];
+#pragma unroll
+    for (int f = 0; f < kBoxFields; ++f) x[f] = __builtin_nontemporal_load(a.in[f] + i);
+    float t[4]; uint32_t fl;
+    box_one(x, t, fl);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(__float_as_uint(t[k]), a.out[k] + i);
+    __builtin_nontemporal_store(fl, a.out[4] + i);
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void k_tri_tiled(const float *__restrict__ in, uint32_t *__restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t tile = i / T, w = i % T;
+    const float *p = in + tile * (uint64_t)(16 * T) + w;
+    float x[kTriFields];
+#pragma unroll
+    for (int f = 0; f < kTriFields; ++f) x[f] = __builtin_nontemporal_load(p + f * T);
+    const uint32_t kk = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p + 15 * T)) & 0x3Fu;
+    float tn, td; uint32_t h;
+    tri_one(x, kk, tn, td, h);
+    uint32_t *q = out + tile * (uint64_t)(3 * T) + w;
+    __builtin_nontemporal_store(__float_as_uint(tn), q);
+    __builtin_nontemporal_store(__float_as_uint(td), q + T);
+    __builtin_nontemporal_store(h, q + 2 * T);
+}
+struct TPtrs { const float *in[16]; uint32_t *out[3]; };
+__global__ __launch_bounds__(256) void k_tri_plain(TPtrs a, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float x[kTriFields];
+#pragma unroll
+    for (int f = 0; f < kTriFields; ++f) x[f] = __builtin_nontemporal_load(a.in[f] + i);
+    const uint32_t kk = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(a.in[15] + i)) & 0x3Fu;
+    float tn, td; uint32_t h;
+    tri_one(x, kk, tn, td, h);
+    __builtin_nontemporal_store(__float_as_uint(tn), a.out[0] + i);
+    __builtin_nontemporal_store(__float_as_uint(td), a.out[1] + i);
+    __builtin_nontemporal_store(h, a.out[2] + i);
+}
+
+__global__ void k_fill(float *p, uint64_t n, uint32_t seed) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = (float)(h & 0xFFFFFF) / 16777216.0f * 200.0f - 100.0f;
+    }
+}
+
+static unsigned lds_for(int w) { return w >= 99 ? 0u : (128u / (unsigned)w) * 1280u; }
+
+template <typename F> static double time_ms(F launch, int warm, int reps) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < warm; ++i) launch();
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) launch();
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipGetLastError());
+    return ms / reps;
+}
+
+int main(int argc, char **argv) {
+    std::vector<int> sizes;
+    for (int i = 1; i < argc; ++i) sizes.push_back(atoi(argv[i]));
+    if (sizes.empty()) sizes = {22, 24, 26};
+    for (int lg : sizes) {
+        const uint64_t n = 1ull << lg;
+        float *in; uint32_t *out;
+        const uint64_t padded = n + 32768;  // whole tiles for every tile size up to 32768 ops
+        CK(hipMalloc(&in, padded * kBoxFields * 4)); CK(hipMalloc(&out, padded * 5 * 4));
+        hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, in, padded * kBoxFields, 12345u);
+        CK(hipDeviceSynchronize());
+        const unsigned blocks = (unsigned)((n + 255) / 256);
+        const int caps[] = {3, 4, 5, 6};
+        for (int w : caps) {
+            const unsigned lds = lds_for(w);
+            double ms;
+#define RUN(T) ms = time_ms([&] { hipLaunchKernelGGL((k_tiled1<T>), dim3(blocks), dim3(256), lds, 0, in, out, n); }, 10, 40); \
+            printf("box n 2^%d cap %2d  tiled T=%-7d %.4f ms frac %.4f\n", lg, w, T, ms, n * 156.0 / ms / 1e6 / 8000.0);
+            RUN(4096) RUN(6144) RUN(8192) RUN(10240) RUN(12288)
+#define RUNV(T, V) ms = time_ms([&] { hipLaunchKernelGGL((k_tiled<T, V>), dim3(blocks / V), dim3(256), lds, 0, in, out, n); }, 10, 40); \
+            printf("box n 2^%d cap %2d  tiled T=%-7d V=%d %.4f ms frac %.4f\n", lg, w, T, V, ms, n * 156.0 / ms / 1e6 / 8000.0);
+            RUNV(8192, 2) RUNV(8192, 4)
+            TPtrs a; for (int f = 0; f < 16; ++f) a.in[f] = in + f * n; for (int k = 0; k < 3; ++k) a.out[k] = out + k * n;
+            ms = time_ms([&] { hipLaunchKernelGGL(k_tri_plain, dim3(blocks), dim3(256), lds, 0, a, n); }, 10, 40);
+            printf("tri n 2^%d cap %2d  plain         %.4f ms frac %.4f\n", lg, w, ms, n * 76.0 / ms / 1e6 / 8000.0);
+#define RUNT(T) ms = time_ms([&] { hipLaunchKernelGGL((k_tri_tiled<T>), dim3(blocks), dim3(256), lds, 0, in, out, n); }, 10, 40); \
+            printf("tri n 2^%d cap %2d  tiled T=%-7d %.4f ms frac %.4f\n", lg, w, T, ms, n * 76.0 / ms / 1e6 / 8000.0);
+            RUNT(2048) RUNT(4096) RUNT(8192) RUNT(16384) RUNT(32768)
+            fflush(stdout);
+        }
+        CK(hipFree(in)); CK(hipFree(out));
+    }
+    return 0;
+}
