@@ -117,15 +117,45 @@ def parse():
     p.add_argument("--strong-log2-ops", type=int, default=28, help="units of the sharded mixed stream (whole job)")
     p.add_argument("--edge-per-class", type=float, default=0.01, help="fraction of the ops of the edge streams in each edge class")
     p.add_argument("--no-extras", action="store_true", help="default line without the edge streams, the sharded 2^28 stream and k-NN")
+    p.add_argument("--layout", default="tiled", choices=["plain", "tiled"],
+                   help="box / triangle segments as one tiled buffer per segment ([tile][word][8192 ops], RT_DP_F_BOX_TILED / "
+                        "RT_DP_F_TRI_TILED: the layout the library recommends) or as one array per operand (plain); the default "
+                        "line reports both")
     p.add_argument("--verify", action="store_true", help="sharded mixed stream: also evaluate the whole stream on rank 0 and compare it with the "
                                                          "shards' results put together (small sizes only: results travel through host memory)")
-    return p.parse_args()
+    a = p.parse_args()
+    if a.stagger_kib:
+        a.layout = "plain"      # the spacing of the operand arrays is a property of the plain layout only
+    return a
 
 
-def make_batches(n, dev, which, stagger_kib=0, derive=False, launch_ops=0, edge=0.0):
+def tiled_box(ctx, batch, fields, n, dev):
+    """Puts the box segment of `batch` into tiled form: the operands are packed from `fields` (which the caller may free)."""
+    operands = torch.empty(capi.tiled_words(n, capi.BOX_TILE_IN_WORDS), dtype=torch.float32, device=dev)
+    results = torch.empty(capi.tiled_words(n, capi.BOX_TILE_OUT_WORDS), dtype=torch.int32, device=dev)
+    src = [f if f is not None else fields[0] for f in fields]     # derive mode: the inv words are never read
+    torch.cuda.synchronize()                                      # the fields were produced on torch's stream
+    ctx.tile_pack(src, operands, n)
+    ctx.synchronize()
+    batch.set_box_tiled(operands, results, n)
+    batch.box_tiled = (operands, results)
+
+
+def tiled_tri(ctx, batch, fields, k, n, dev):
+    operands = torch.empty(capi.tiled_words(n, capi.TRI_TILE_IN_WORDS), dtype=torch.float32, device=dev)
+    results = torch.empty(capi.tiled_words(n, capi.TRI_TILE_OUT_WORDS), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.tile_pack(list(fields) + [k if k is not None else fields[0]], operands, n)
+    ctx.synchronize()
+    batch.set_tri_tiled(operands, results, n)
+    batch.tri_tiled = (operands, results)
+
+
+def make_batches(n, dev, which, stagger_kib=0, derive=False, launch_ops=0, edge=0.0, layout="plain", ctx=None):
     """Resident operand / result arrays and one capi.Batch per workload."""
     out = {}
     i32, f32 = torch.int32, torch.float32
+    tiled = layout == "tiled"
 
     def box(n_):
         fields = synth.box_stream(n_, 20241008, dev, edge)
@@ -159,13 +189,20 @@ def make_batches(n, dev, which, stagger_kib=0, derive=False, launch_ops=0, edge=
     if "box" in which:
         b = capi.Batch().derive_ray(derive)
         fields, tmin, flags = box(n)
-        b.set_box(fields, tmin, flags, launch_ops or None)
+        if tiled:
+            del tmin, flags
+            tiled_box(ctx, b, fields, launch_ops or n, dev)
+        else:
+            b.set_box(fields, tmin, flags, launch_ops or None)
         b.box_fields = fields
         out["box"] = (b.finalize(), {"box": launch_ops or n})
     if "tri" in which:
         b = capi.Batch().derive_ray(derive)   # derive: the three shear arrays stand in for the ray direction
         t = tri(n)
-        b.set_tri(*t)
+        if tiled:
+            tiled_tri(ctx, b, t[0], t[1], n, dev)
+        else:
+            b.set_tri(*t)
         b.tri_fields, b.tri_k = t[0], t[1]
         out["tri"] = (b.finalize(), {"tri": n})
     if "euclid" in which:
@@ -182,8 +219,14 @@ def make_batches(n, dev, which, stagger_kib=0, derive=False, launch_ops=0, edge=
         # opcode ~ U{0..3}: a quarter of the stream per opcode, opcode-sorted segments
         q = n // 4
         b = capi.Batch().derive_ray(derive)
-        b.set_box(*box(q))
-        b.set_tri(*tri(q))
+        if tiled:
+            tiled_box(ctx, b, box(q)[0], q, dev)
+            t = tri(q)
+            tiled_tri(ctx, b, t[0], t[1], q, dev)
+            del t
+        else:
+            b.set_box(*box(q))
+            b.set_tri(*tri(q))
         e, a = euc(q), ang(q)
         b.set_euclid(*e)
         b.set_angular(*a)
@@ -270,7 +313,7 @@ def run(ctx, batch, steps, warmup, dist):
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
 
 
-def roofline(counts, dev_ms, measured_format=True):
+def roofline(counts, dev_ms, measured_format=True, layout="plain"):
     """The launch against the HBM roof.  `achieved` is live (algorithmic bytes / HIP-event time of this run); `traffic` and
     `valu_issue_fraction` are NOT measured in this run: they are the per-unit figures of the committed rocprofv3 --pmc passes
     (profiles/traffic.json) scaled to this launch, and `traffic_source` says so."""
@@ -281,10 +324,11 @@ def roofline(counts, dev_ms, measured_format=True):
     if measured_format and os.path.exists(TRAFFIC_FILE):   # the committed passes measured the plain operand format
         try:
             per_unit = json.load(open(TRAFFIC_FILE))
-            r["traffic"] = int(sum(per_unit[k]["hbm_bytes_per_unit"] * v for k, v in counts.items()))
+            key = lambda k: k + "_tiled" if layout == "tiled" and k in ("box", "tri") else k   # the tiled kernels have passes of their own
+            r["traffic"] = int(sum(per_unit[key(k)]["hbm_bytes_per_unit"] * v for k, v in counts.items()))
             if len(counts) == 1:
                 (k,) = counts.keys()
-                r["valu_issue_fraction"] = per_unit[k].get("valu_issue_fraction")
+                r["valu_issue_fraction"] = per_unit[key(k)].get("valu_issue_fraction")
             r["traffic_source"] = "profiles/traffic.json (%s), per-unit counter figures x the units of this launch; not re-measured in this run" % per_unit.get(
                 "_source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes")
         except Exception:
@@ -504,7 +548,7 @@ def run_knn(a, world, rank, local, dev):
     dist_util.shutdown()
 
 
-def make_strong_mixed(total, world, rank, dev, keep_whole=False):
+def make_strong_mixed(total, world, rank, dev, keep_whole=False, layout="plain", ctx=None):
     """The config-4 stream: `total` units, a quarter per opcode, opcode-sorted; this rank keeps the shard that
     shard.plan gives it (contiguous ranges, beat segments cut on vector-pair boundaries: every shard starts from +0
     accumulators and no collective touches the data path).  Every rank draws the same whole stream and keeps its part.
@@ -539,21 +583,30 @@ def make_strong_mixed(total, world, rank, dev, keep_whole=False):
     tri, trik = [cut(f, plan["tri"]) for f in tf], cut(tk, plan["tri"])
     del tf, tk
     torch.cuda.empty_cache()
-    b = batch_from(box, tri, trik, e, g, dev)
     counts = {"box": int(box[0].shape[0]), "tri": int(tri[0].shape[0]), "euclid": int(e[2].shape[0]), "angular": int(g[2].shape[0])}
+    b = batch_from(box, tri, trik, e, g, dev, layout, ctx)
+    del box, tri, trik
+    torch.cuda.empty_cache()
     return b, counts, {"box": q, "tri": q, "euclid": ne, "angular": na}, whole
 
 
-def batch_from(box, tri, trik, euc, ang, dev):
-    """One mixed batch over the given operand arrays with freshly allocated result arrays (kept in batch.results)."""
+def batch_from(box, tri, trik, euc, ang, dev, layout="plain", ctx=None):
+    """One mixed batch over the given operand arrays with freshly allocated result arrays (kept in batch.results).
+    layout "tiled": the box and triangle segments are packed into tiled buffers (the given arrays are not referenced)."""
     f32, i32 = torch.float32, torch.int32
     nb, nt, ne, na = int(box[0].shape[0]), int(tri[0].shape[0]), int(euc[2].shape[0]), int(ang[2].shape[0])
-    res = {"tmin": [torch.empty(nb, dtype=f32, device=dev) for _ in range(4)], "flags": torch.empty(nb, dtype=i32, device=dev),
-           "t_num": torch.empty(nt, dtype=f32, device=dev), "t_denom": torch.empty(nt, dtype=f32, device=dev), "hit": torch.empty(nt, dtype=i32, device=dev),
-           "acc": torch.empty(ne, dtype=f32, device=dev), "dot": torch.empty(na, dtype=f32, device=dev), "norm": torch.empty(na, dtype=f32, device=dev)}
+    res = {"acc": torch.empty(ne, dtype=f32, device=dev), "dot": torch.empty(na, dtype=f32, device=dev), "norm": torch.empty(na, dtype=f32, device=dev)}
     b = capi.Batch()
-    b.set_box(box, res["tmin"], res["flags"])
-    b.set_tri(tri, trik, res["t_num"], res["t_denom"], res["hit"])
+    if layout == "tiled":
+        tiled_box(ctx, b, box, nb, dev)
+        tiled_tri(ctx, b, tri, trik, nt, dev)
+        res["tiled"] = (nb, nt)
+    else:
+        res.update({"tmin": [torch.empty(nb, dtype=f32, device=dev) for _ in range(4)], "flags": torch.empty(nb, dtype=i32, device=dev),
+                    "t_num": torch.empty(nt, dtype=f32, device=dev), "t_denom": torch.empty(nt, dtype=f32, device=dev),
+                    "hit": torch.empty(nt, dtype=i32, device=dev)})
+        b.set_box(box, res["tmin"], res["flags"])
+        b.set_tri(tri, trik, res["t_num"], res["t_denom"], res["hit"])
     b.set_euclid(euc[0], euc[1], euc[2], res["acc"])
     b.set_angular(ang[0], ang[1], ang[2], res["dot"], res["norm"])
     b.finalize()
@@ -561,14 +614,26 @@ def batch_from(box, tri, trik, euc, ang, dev):
     return b
 
 
-def result_list(res):
+def result_list(batch, ctx):
+    """The result arrays of a batch_from batch in one fixed order; tiled segments are unpacked into plain arrays first."""
+    res = batch.results
+    if "tiled" in res:
+        nb, nt = res["tiled"]
+        dev = res["acc"].device
+        box = [torch.empty(nb, dtype=torch.int32, device=dev) for _ in range(5)]
+        tri = [torch.empty(nt, dtype=torch.int32, device=dev) for _ in range(3)]
+        ctx.tile_unpack(batch.box_tiled[1], box, nb)
+        ctx.tile_unpack(batch.tri_tiled[1], tri, nt)
+        ctx.synchronize()
+        return box + tri + [res["acc"], res["dot"], res["norm"]]
     return res["tmin"] + [res["flags"], res["t_num"], res["t_denom"], res["hit"], res["acc"], res["dot"], res["norm"]]
 
 
-def strong_mixed_measure(a, ctx, world, rank, dev, dist, log2_total, steps, warmup):
+def strong_mixed_measure(a, ctx, world, rank, dev, dist, log2_total, steps, warmup, layout=None):
     """Runs the sharded mixed stream; returns the result block (identical on every rank)."""
     total = 1 << log2_total
-    batch, counts, whole_counts, whole = make_strong_mixed(total, world, rank, dev, keep_whole=a.verify)
+    layout = layout or a.layout
+    batch, counts, whole_counts, whole = make_strong_mixed(total, world, rank, dev, keep_whole=a.verify, layout=layout, ctx=ctx)
     torch.cuda.synchronize()
     ctx.reset()
     wall, dev_ms = run(ctx, batch, steps, warmup, dist)
@@ -576,23 +641,24 @@ def strong_mixed_measure(a, ctx, world, rank, dev, dist, log2_total, steps, warm
     block = {"value": round(units * steps / wall, 1), "unit": "ops/s", "ms_per_step": round(wall / steps * 1e3, 4), "kernel_ms": round(dev_ms, 4),
              "steps": steps, "warmup": warmup, "scaling": "strong", "units_whole_job": units, "units_this_gpu": sum(counts.values()),
              "workload": "mixed: 2^%d-unit opcode-sorted stream (a quarter per opcode), cut by shard.plan into %d pair-aligned shard(s), no collective" % (log2_total, world),
-             "roofline": roofline(counts, dev_ms)}
+             "layout": layout, "roofline": roofline(counts, dev_ms, True, layout)}
     if a.verify:
         # the shards' results, put together in rank order, must be the whole stream's results (computed on rank 0 in one batch)
         ctx.reset()
         ctx.launch(batch, bench_stream().cuda_stream)
         torch.cuda.synchronize()
-        mine = [t.cpu().numpy().view(np.uint32) for t in result_list(batch.results)]
+        mine = [t.cpu().numpy().view(np.uint32) for t in result_list(batch, ctx)]
         parts = dist_util.gather_objects(mine)
         ok = None
         if rank == 0:
+            # the whole stream always in the plain layout: a tiled run is thereby also checked against the plain kernels
             wb = batch_from(whole["box"], whole["tri"], whole["trik"], (whole["ea"], whole["eb"], whole["ectl"]),
                             (whole["aq"], whole["ac"], whole["actl"]), dev)
             c2 = capi.Context(device=torch.cuda.current_device())
             c2.launch(wb, bench_stream().cuda_stream)
             torch.cuda.synchronize()
+            want = [t.cpu().numpy().view(np.uint32) for t in result_list(wb, c2)]
             c2.close()
-            want = [t.cpu().numpy().view(np.uint32) for t in result_list(wb.results)]
             ok = all(np.array_equal(np.concatenate([p[k] for p in parts]), want[k]) for k in range(len(want)))
         block["verified_against_whole_stream"] = ok
     del batch
@@ -670,7 +736,7 @@ def main():
         which, only_edge = [a.only.split("_")[0]], a.edge_per_class
     if a.derive:
         BYTES.update(box=144, tri=72)
-    batches = make_batches(n, dev, which, a.stagger_kib, bool(a.derive), a.launch_ops, only_edge)
+    batches = make_batches(n, dev, which, a.stagger_kib, bool(a.derive), a.launch_ops, only_edge, a.layout, ctx)
     torch.cuda.synchronize()
 
     if a.sweep:
@@ -679,14 +745,15 @@ def main():
         ctx.close()
         return
 
-    plain = not a.derive      # the committed counter passes measured the plain operand format
+    plain = not a.derive      # the committed counter passes measured the operand format without derived fields
     results = {}
     for name in which:
         batch, counts = batches[name]
         wall, dev_ms = run(ctx, batch, a.steps, a.warmup, dist)
         units = sum(counts.values())
         results[name] = {"value": units * world * a.steps / wall, "ms_per_step": wall / a.steps * 1e3, "scaling": "weak",
-                         "kernel_ms": dev_ms, "units_per_gpu": units, "roofline": roofline(counts, dev_ms, plain)}
+                         "kernel_ms": dev_ms, "units_per_gpu": units, "layout": a.layout if name in ("box", "tri", "mixed") else "plain",
+                         "roofline": roofline(counts, dev_ms, plain, a.layout)}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and "box" in batches:
@@ -696,29 +763,59 @@ def main():
         # config 2 / 3 with their edge classes: >= 1 % of the ops in every class, same size as the headline.  The edge
         # streams are written INTO the arrays of the plain batches, so the two runs differ in their operands only and
         # not in where the 39 (19) arrays lie against each other (which alone moves the rate by several per cent)
+        other = "tiled" if a.layout == "plain" else "plain"
+        for name in ("box", "tri"):
+            # the same ops in the other layout (the operands are packed from / kept in the arrays of the batch above)
+            batch, counts = batches[name]
+            ob = capi.Batch().derive_ray(bool(a.derive))
+            if other == "tiled":
+                if name == "box":
+                    tiled_box(ctx, ob, batch.box_fields, n, dev)
+                else:
+                    tiled_tri(ctx, ob, batch.tri_fields, batch.tri_k, n, dev)
+            elif name == "box":
+                ob.set_box(batch.box_fields, [torch.empty(n, dtype=torch.float32, device=dev) for _ in range(4)], torch.empty(n, dtype=torch.int32, device=dev), n)
+            else:
+                ob.set_tri(batch.tri_fields, batch.tri_k, torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev),
+                           torch.empty(n, dtype=torch.int32, device=dev), n)
+            ob.finalize()
+            wall, dev_ms = run(ctx, ob, a.steps, a.warmup, dist)
+            results[name + "_" + other] = {"value": counts[name] * world * a.steps / wall, "ms_per_step": wall / a.steps * 1e3, "scaling": "weak",
+                                           "kernel_ms": dev_ms, "units_per_gpu": counts[name], "layout": other,
+                                           "roofline": roofline(counts, dev_ms, plain, other)}
+            del ob
+            torch.cuda.empty_cache()
         for name in ("box", "tri"):
             batch, counts = batches[name]
             if name == "box":
                 fresh = synth.box_stream(n, 20241008, dev, a.edge_per_class)
                 for dst, src in zip(batch.box_fields, fresh):
                     dst.copy_(src)
+                if a.layout == "tiled":
+                    torch.cuda.synchronize()
+                    ctx.tile_pack(batch.box_fields, batch.box_tiled[0], n)
             else:
                 fresh, fresh_k = synth.tri_stream(n, 20241009, dev, a.edge_per_class)
                 for dst, src in zip(batch.tri_fields, fresh):
                     dst.copy_(src)
                 batch.tri_k.copy_(fresh_k)
+                if a.layout == "tiled":
+                    torch.cuda.synchronize()
+                    ctx.tile_pack(list(batch.tri_fields) + [batch.tri_k], batch.tri_tiled[0], n)
                 del fresh_k
             del fresh
+            ctx.synchronize()
             torch.cuda.synchronize()
             wall, dev_ms = run(ctx, batch, a.steps, a.warmup, dist)
             results[name + "_edge"] = {"value": counts[name] * world * a.steps / wall, "ms_per_step": wall / a.steps * 1e3, "scaling": "weak",
-                                       "kernel_ms": dev_ms, "units_per_gpu": counts[name], "roofline": roofline(counts, dev_ms, plain),
+                                       "kernel_ms": dev_ms, "units_per_gpu": counts[name], "layout": a.layout, "roofline": roofline(counts, dev_ms, plain, a.layout),
                                        "edge_classes": {"per_class": a.edge_per_class, "same_arrays_as": name,
                                                         "classes": synth.BOX_EDGE_CLASSES if name == "box" else synth.TRI_EDGE_CLASSES}}
         del batches, batch
         torch.cuda.empty_cache()
         # config 4: the 2^28-unit mixed stream, one shard per GPU
         extras["mixed_2p%d" % a.strong_log2_ops] = strong_mixed_measure(a, ctx, world, rank, dev, dist, a.strong_log2_ops, a.steps, a.warmup)
+        extras["mixed_2p%d_%s" % (a.strong_log2_ops, other)] = strong_mixed_measure(a, ctx, world, rank, dev, dist, a.strong_log2_ops, a.steps, a.warmup, other)
         # config 5: k-NN, exhaustive and leaf-major
         ksteps, kwarm = max(1, min(a.steps, 5)), max(1, min(a.warmup, 2))
         extras["knn"] = {"exhaustive": knn_measure(a, ctx, world, rank, dev, 0, ksteps, kwarm),
@@ -732,9 +829,11 @@ def main():
         "value": round(r["value"], 1), "unit": "ops/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(r["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %s random ray-vs-4-AABB box ops per GPU, SoA fp32 operands resident in HBM" % (head, size_text)
+        "config": {"workload": "%s: %s random ray-vs-4-AABB box ops per GPU, SoA fp32 operands resident in HBM%s" % (
+                       head, size_text, " in tiles of 8192 ops" if a.layout == "tiled" else "")
                    if head == "box" else "%s, %s units per GPU" % (head, size_text),
-                   "ops_per_gpu": r["units_per_gpu"], "bytes_per_op": BYTES.get(head), "sharding": "independent op streams per GPU, no collective",
+                   "ops_per_gpu": r["units_per_gpu"], "bytes_per_op": BYTES.get(head),
+                   "layout": "one array per operand" if a.layout == "plain" or head not in ("box", "tri", "mixed") else "tiled: one buffer per segment, [tile][word][8192 ops]", "sharding": "independent op streams per GPU, no collective",
                    "tuning": tuning},
         "roofline": r["roofline"],
     }
@@ -742,7 +841,7 @@ def main():
         line["cpu_baseline"] = cpu
         line["per_opcode"] = {k: {"value": round(v["value"], 1), "unit": "ops/s" if k.split("_")[0] in ("box", "tri", "mixed") else "beats/s",
                                   "scaling": v["scaling"], "kernel_ms": round(v["kernel_ms"], 4), "units_per_gpu": v["units_per_gpu"],
-                                  "roofline": v["roofline"], **({"edge_classes": v["edge_classes"]} if "edge_classes" in v else {})}
+                                  "layout": v.get("layout", "plain"), "roofline": v["roofline"], **({"edge_classes": v["edge_classes"]} if "edge_classes" in v else {})}
                               for k, v in results.items()}
         line["per_opcode"].update(extras)
         print(json.dumps(line), flush=True)

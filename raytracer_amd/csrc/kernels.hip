@@ -122,9 +122,19 @@ __global__ __launch_bounds__(256) void k_box_tiled(const float *__restrict__ in,
     const uint32_t w = (uint32_t)(i % kTileOps);
     const float *p = in + tile * (uint64_t)(kBoxFields * kTileOps) + w;
     float x[kBoxFields];
+    // How a wave hands its 34 loads to the memory pipeline matters (measured, 2^22 .. 2^26 ops, 3 workgroups per CU,
+    // fractions of the HBM peak): all loads back to back from a scalar tile base with one shared lane offset 0.82;
+    // per-lane 64-bit addresses (two vector adds between loads) 0.845; a few idle cycles after each load 0.855 .. 0.86,
+    // flat from 2 to 10 cycles, falling off from 16 (0.83, 0.75 at 32).  Waiting for the first one or two loads
+    // before the rest go out gives the same 0.855 .. 0.86: what helps is that the waves of a CU do not all push their
+    // bursts at once.  (With the idle cycles in place the compiler also tests the ray direction as soon as it has
+    // arrived, i.e. this kernel does both.)  The triangle kernel's 16 loads gain nothing from either.
 #pragma unroll
-    for (int f = 0; f < kBoxFields; ++f)
-        if (!DERIVE || f < 6 || f > 8) x[f] = ld<float, NT>(p + (size_t)f * kTileOps);
+    for (int f = 0; f < kBoxFields; ++f) {
+        if (DERIVE && f >= 6 && f <= 8) continue;
+        x[f] = ld<float, NT>(p + (size_t)f * kTileOps);
+        asm volatile("s_nop 5");
+    }
     if (DERIVE) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) x[6 + c] = canon_nan(1.0f / x[3 + c]);

@@ -56,6 +56,144 @@ __global__ __launch_bounds__(256) void k_tiled1(const float *__restrict__ in, ui
     __builtin_nontemporal_store(fl, q + 4 * T);
 }
 
+template <typename T> __device__ __forceinline__ T ld_sb(const void *uniform_base, uint32_t lane_off) {
+    typedef const T __attribute__((address_space(1))) *G;
+    uintptr_t b = reinterpret_cast<uintptr_t>(uniform_base);
+    asm volatile("" : "+s"(b));
+    return __builtin_nontemporal_load((G)b + lane_off);
+}
+template <typename T> __device__ __forceinline__ void st_sb(void *uniform_base, uint32_t lane_off, T v) {
+    typedef T __attribute__((address_space(1))) *G;
+    uintptr_t b = reinterpret_cast<uintptr_t>(uniform_base);
+    asm volatile("" : "+s"(b));
+    __builtin_nontemporal_store(v, (G)b + lane_off);
+}
+// scalar tile base + one shared lane offset
+template <int T>
+__global__ __launch_bounds__(256) void k_tiled_s(const float *__restrict__ in, uint32_t *__restrict__ out, uint64_t n) {
+    const uint64_t first = (uint64_t)blockIdx.x * 256u;
+    if (first + threadIdx.x >= n) return;
+    const uint64_t tile = first / T;
+    const uint32_t w = (uint32_t)(first % T) + threadIdx.x;
+    const float *p = in + tile * (uint64_t)(kBoxFields * T);
+    float x[kBoxFields];
+#pragma unroll
+    for (int f = 0; f < kBoxFields; ++f) x[f] = ld_sb<float>(p + (size_t)f * T, w);
+    float t[4]; uint32_t fl;
+    box_one(x, t, fl);
+    uint32_t *q = out + tile * (uint64_t)(5 * T);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st_sb<uint32_t>(q + (size_t)k * T, w, __float_as_uint(t[k]));
+    st_sb<uint32_t>(q + (size_t)4 * T, w, fl);
+}
+
+// scalar base, with PACE idle cycles (s_sleep units of 64 clocks are too coarse: s_nop) after each load
+template <int T, int PACE>
+__global__ __launch_bounds__(256) void k_tiled_p(const float *__restrict__ in, uint32_t *__restrict__ out, uint64_t n) {
+    const uint64_t first = (uint64_t)blockIdx.x * 256u;
+    if (first + threadIdx.x >= n) return;
+    const uint64_t tile = first / T;
+    const uint32_t w = (uint32_t)(first % T) + threadIdx.x;
+    const float *p = in + tile * (uint64_t)(kBoxFields * T);
+    float x[kBoxFields];
+#pragma unroll
+    for (int f = 0; f < kBoxFields; ++f) {
+        x[f] = ld_sb<float>(p + (size_t)f * T, w);
+        if (PACE == 1) asm volatile("s_nop 3");
+        if (PACE == 2) asm volatile("s_nop 7");
+        if (PACE == 3) asm volatile("s_nop 15");
+        if (PACE == 4) asm volatile("s_nop 15\n s_nop 15");
+    }
+    float t[4]; uint32_t fl;
+    box_one(x, t, fl);
+    uint32_t *q = out + tile * (uint64_t)(5 * T);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st_sb<uint32_t>(q + (size_t)k * T, w, __float_as_uint(t[k]));
+    st_sb<uint32_t>(q + (size_t)4 * T, w, fl);
+}
+template <int T>
+__global__ __launch_bounds__(256) void k_tri_tiled_s(const float *__restrict__ in, uint32_t *__restrict__ out, uint64_t n) {
+    const uint64_t first = (uint64_t)blockIdx.x * 256u;
+    if (first + threadIdx.x >= n) return;
+    const uint64_t tile = first / T;
+    const uint32_t w = (uint32_t)(first % T) + threadIdx.x;
+    const float *p = in + tile * (uint64_t)(16 * T);
+    float x[kTriFields];
+#pragma unroll
+    for (int f = 0; f < kTriFields; ++f) x[f] = ld_sb<float>(p + (size_t)f * T, w);
+    const uint32_t kk = ld_sb<uint32_t>(p + (size_t)15 * T, w) & 0x3Fu;
+    float tn, td; uint32_t h;
+    tri_one(x, kk, tn, td, h);
+    uint32_t *q = out + tile * (uint64_t)(3 * T);
+    st_sb<uint32_t>(q, w, __float_as_uint(tn));
+    st_sb<uint32_t>(q + (size_t)T, w, __float_as_uint(td));
+    st_sb<uint32_t>(q + (size_t)2 * T, w, h);
+}
+
+// vector addressing with PACE idle cycles after each load
+template <int T, int PACE>
+__global__ __launch_bounds__(256) void k_tiled_vp(const float *__restrict__ in, uint32_t *__restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t tile = i / T, w = i % T;
+    const float *p = in + tile * (uint64_t)(kBoxFields * T) + w;
+    float x[kBoxFields];
+#pragma unroll
+    for (int f = 0; f < kBoxFields; ++f) {
+        x[f] = __builtin_nontemporal_load(p + f * T);
+        if (PACE > 0) asm volatile("s_nop %0" :: "n"(PACE - 1));
+    }
+    float t[4]; uint32_t fl;
+    box_one(x, t, fl);
+    uint32_t *q = out + tile * (uint64_t)(5 * T) + w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(__float_as_uint(t[k]), q + k * T);
+    __builtin_nontemporal_store(fl, q + 4 * T);
+}
+
+template <int T, int PACE>
+__global__ __launch_bounds__(256) void k_tri_tiled_vp(const float *__restrict__ in, uint32_t *__restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t tile = i / T, w = i % T;
+    const float *p = in + tile * (uint64_t)(16 * T) + w;
+    float x[kTriFields];
+#pragma unroll
+    for (int f = 0; f < kTriFields; ++f) {
+        x[f] = __builtin_nontemporal_load(p + f * T);
+        if (PACE > 0) asm volatile("s_nop %0" :: "n"(PACE - 1));
+    }
+    const uint32_t kk = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p + 15 * T)) & 0x3Fu;
+    float tn, td; uint32_t h;
+    tri_one(x, kk, tn, td, h);
+    uint32_t *q = out + tile * (uint64_t)(3 * T) + w;
+    __builtin_nontemporal_store(__float_as_uint(tn), q);
+    __builtin_nontemporal_store(__float_as_uint(td), q + T);
+    __builtin_nontemporal_store(h, q + 2 * T);
+}
+
+// vector addressing; SPLIT > 0: wait for the first SPLIT loads before issuing the rest; NOP > 0: s_nop builtin after each load
+template <int T, int SPLIT, int NOP>
+__global__ __launch_bounds__(256) void k_tiled_x(const float *__restrict__ in, uint32_t *__restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t tile = i / T, w = i % T;
+    const float *p = in + tile * (uint64_t)(kBoxFields * T) + w;
+    float x[kBoxFields];
+#pragma unroll
+    for (int f = 0; f < kBoxFields; ++f) {
+        x[f] = __builtin_nontemporal_load(p + f * T);
+        if (NOP > 0) asm volatile("s_nop %0" :: "n"(NOP - 1));
+        if (SPLIT > 0 && f == SPLIT - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    float t[4]; uint32_t fl;
+    box_one(x, t, fl);
+    uint32_t *q = out + tile * (uint64_t)(5 * T) + w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(__float_as_uint(t[k]), q + k * T);
+    __builtin_nontemporal_store(fl, q + 4 * T);
+}
+
 struct Ptrs { const float *in[kBoxFields]; uint32_t *out[5]; };
 __global__ __launch_bounds__(256) void k_plain(Ptrs a, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
@@ -102,6 +240,23 @@ __global__ __launch_bounds__(256) void k_tri_plain(TPtrs a, uint64_t n) {
     __builtin_nontemporal_store(h, a.out[2] + i);
 }
 
+template <int PACE>
+__global__ __launch_bounds__(256) void k_plain_p(Ptrs a, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float x[kBoxFields];
+#pragma unroll
+    for (int f = 0; f < kBoxFields; ++f) {
+        x[f] = __builtin_nontemporal_load(a.in[f] + i);
+        if (PACE > 0) asm volatile("s_nop %0" :: "n"(PACE - 1));
+    }
+    float t[4]; uint32_t fl;
+    box_one(x, t, fl);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(__float_as_uint(t[k]), a.out[k] + i);
+    __builtin_nontemporal_store(fl, a.out[4] + i);
+}
+
 __global__ void k_fill(float *p, uint64_t n, uint32_t seed) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t h = (uint32_t)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
@@ -134,22 +289,22 @@ int main(int argc, char **argv) {
         hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, in, padded * kBoxFields, 12345u);
         CK(hipDeviceSynchronize());
         const unsigned blocks = (unsigned)((n + 255) / 256);
-        const int caps[] = {3, 4, 5, 6};
+        const int caps[] = {3, 4};
+        for (int round = 0; round < 2; ++round)
         for (int w : caps) {
             const unsigned lds = lds_for(w);
             double ms;
-#define RUN(T) ms = time_ms([&] { hipLaunchKernelGGL((k_tiled1<T>), dim3(blocks), dim3(256), lds, 0, in, out, n); }, 10, 40); \
-            printf("box n 2^%d cap %2d  tiled T=%-7d %.4f ms frac %.4f\n", lg, w, T, ms, n * 156.0 / ms / 1e6 / 8000.0);
-            RUN(4096) RUN(6144) RUN(8192) RUN(10240) RUN(12288)
-#define RUNV(T, V) ms = time_ms([&] { hipLaunchKernelGGL((k_tiled<T, V>), dim3(blocks / V), dim3(256), lds, 0, in, out, n); }, 10, 40); \
-            printf("box n 2^%d cap %2d  tiled T=%-7d V=%d %.4f ms frac %.4f\n", lg, w, T, V, ms, n * 156.0 / ms / 1e6 / 8000.0);
-            RUNV(8192, 2) RUNV(8192, 4)
-            TPtrs a; for (int f = 0; f < 16; ++f) a.in[f] = in + f * n; for (int k = 0; k < 3; ++k) a.out[k] = out + k * n;
-            ms = time_ms([&] { hipLaunchKernelGGL(k_tri_plain, dim3(blocks), dim3(256), lds, 0, a, n); }, 10, 40);
-            printf("tri n 2^%d cap %2d  plain         %.4f ms frac %.4f\n", lg, w, ms, n * 76.0 / ms / 1e6 / 8000.0);
-#define RUNT(T) ms = time_ms([&] { hipLaunchKernelGGL((k_tri_tiled<T>), dim3(blocks), dim3(256), lds, 0, in, out, n); }, 10, 40); \
-            printf("tri n 2^%d cap %2d  tiled T=%-7d %.4f ms frac %.4f\n", lg, w, T, ms, n * 76.0 / ms / 1e6 / 8000.0);
-            RUNT(2048) RUNT(4096) RUNT(8192) RUNT(16384) RUNT(32768)
+#define BOXRUN(NAME, K) ms = time_ms([&] { hipLaunchKernelGGL(K, dim3(blocks), dim3(256), lds, 0, in, out, n); }, 10, 40); \
+            printf("box n 2^%d cap %2d  %-20s %.4f ms frac %.4f\n", lg, w, NAME, ms, n * 156.0 / ms / 1e6 / 8000.0);
+            Ptrs a; for (int f = 0; f < kBoxFields; ++f) a.in[f] = in + f * n; for (int k = 0; k < 5; ++k) a.out[k] = out + k * n;
+#define PLRUN(NAME, K) ms = time_ms([&] { hipLaunchKernelGGL(K, dim3(blocks), dim3(256), lds, 0, a, n); }, 10, 40); \
+            printf("box n 2^%d cap %2d  %-20s %.4f ms frac %.4f\n", lg, w, NAME, ms, n * 156.0 / ms / 1e6 / 8000.0);
+            PLRUN("plain pace 0", (k_plain_p<0>))
+            PLRUN("plain pace 2", (k_plain_p<2>))
+            PLRUN("plain pace 6", (k_plain_p<6>))
+            PLRUN("plain pace 10", (k_plain_p<10>))
+            PLRUN("plain pace 16", (k_plain_p<16>))
+            BOXRUN("tiled pace 6", (k_tiled_vp<8192, 6>))
             fflush(stdout);
         }
         CK(hipFree(in)); CK(hipFree(out));

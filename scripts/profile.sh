@@ -18,6 +18,12 @@ run() { # name, limit, command...
 
 BENCH="python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
 run kernel_trace 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $BENCH
+for wl in box tri; do   # the same two opcodes over one array per operand
+    run "fetch_${wl}_plain" 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_${wl}_plain" -- $BENCH --only $wl --layout plain --steps 3 --warmup 1
+    run "write_${wl}_plain" 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_${wl}_plain" -- $BENCH --only $wl --layout plain --steps 3 --warmup 1
+    run "valu_${wl}_plain" 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d "$OUT/pmc_valu_${wl}_plain" -- $BENCH --only $wl --layout plain --steps 3 --warmup 1
+    run "grbm_${wl}_plain" 120 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_grbm_${wl}_plain" -- $BENCH --only $wl --layout plain --steps 3 --warmup 1
+done
 for wl in box tri euclid angular; do
     run "fetch_$wl" 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_$wl" -- $BENCH --only $wl --steps 3 --warmup 1
     run "write_$wl" 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_$wl" -- $BENCH --only $wl --steps 3 --warmup 1

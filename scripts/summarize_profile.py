@@ -110,7 +110,10 @@ ffac = sorted(fcal.values())[len(fcal) // 2] if fcal else 2.0
 wfac = sorted(wcal.values())[len(wcal) // 2] if wcal else 1.0
 lines.append("\nFETCH_SIZE correction used: x%.3f (KiB -> bytes: x1024, then the factor).  WRITE_SIZE correction: x%.3f.\n" % (ffac, wfac))
 
-UNITS = {"box": (("rtdp::k_box",), 156, 136, 20), "tri": (("rtdp::k_tri",), 76, 64, 12),
+# traffic.json keys: the layout bench.py runs by default is tiled, so "box" / "tri" passes see the tiled kernels and the
+# "_plain" passes the kernels over one array per operand; bench.py looks the per-unit figures up as <opcode>_tiled / <opcode>
+UNITS = {"box_tiled": (("rtdp::k_box_tiled<",), 156, 136, 20), "tri_tiled": (("rtdp::k_tri_tiled<",), 76, 64, 12),
+         "box": (("rtdp::k_box<",), 156, 136, 20), "tri": (("rtdp::k_tri<",), 76, 64, 12),
          "euclid": (("rtdp::k_vec<true", "rtdp::k_vec_chain<true"), 136, 132, 4),
          "angular": (("rtdp::k_vec<false", "rtdp::k_vec_chain<false"), 76, 68, 8)}
 lines += ["## Datapath kernels (headline batch of each opcode)\n",
@@ -126,11 +129,14 @@ for line in open(os.path.join(src, "log.txt")):
         for k, v in d.get("per_opcode", {}).items():
             if "units_per_gpu" in v:
                 units_log[k] = v["units_per_gpu"]
+PASS = {"box_tiled": "box", "tri_tiled": "tri", "box": "box_plain", "tri": "tri_plain", "euclid": "euclid", "angular": "angular"}   # directory suffix of the passes
 for op, (prefix, total, rd, wr) in UNITS.items():
-    fe = {k: v for k, v in pmc("pmc_fetch_%s/*/*counter_collection.csv" % op, "FETCH_SIZE").items() if k[0].startswith(prefix)}
-    we = {k: v for k, v in pmc("pmc_write_%s/*/*counter_collection.csv" % op, "WRITE_SIZE").items() if k[0].startswith(prefix)}
-    if not fe or not we or op not in units_log:
+    fe = {k: v for k, v in pmc("pmc_fetch_%s/*/*counter_collection.csv" % PASS[op], "FETCH_SIZE").items() if k[0].startswith(prefix)}
+    we = {k: v for k, v in pmc("pmc_write_%s/*/*counter_collection.csv" % PASS[op], "WRITE_SIZE").items() if k[0].startswith(prefix)}
+    base = op.split("_")[0]
+    if not fe or not we or base not in units_log:
         continue
+    units_log[op] = units_log[base]
     key = max(fe, key=lambda k: k[1])  # the main launch (largest grid), not the tail launch
     n = units_log[op]
     fb = med(fe[key]) * 1024 * ffac / n
@@ -159,10 +165,10 @@ lines += ["\n## VALU issue and clock (own counter passes: `--pmc SQ_INSTS_VALU S
           " instruction here but occupies the SIMD like two, so the fraction understates kernels that use them.  Clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time.\n",
           "| opcode | VALU instructions per wave | per unit of work | VALU issue fraction | clock under the kernel |\n|---|---|---|---|---|"]
 for op, (prefix, total, rd, wr) in UNITS.items():
-    iv = pmc_timed("pmc_valu_%s/*/*counter_collection.csv" % op, "SQ_INSTS_VALU", prefix)
-    wv = pmc_timed("pmc_valu_%s/*/*counter_collection.csv" % op, "SQ_WAVES", prefix)
-    gr = pmc_timed("pmc_grbm_%s/*/*counter_collection.csv" % op, "GRBM_GUI_ACTIVE", prefix)
-    if not iv or not wv or op not in units_log:
+    iv = pmc_timed("pmc_valu_%s/*/*counter_collection.csv" % PASS[op], "SQ_INSTS_VALU", prefix)
+    wv = pmc_timed("pmc_valu_%s/*/*counter_collection.csv" % PASS[op], "SQ_WAVES", prefix)
+    gr = pmc_timed("pmc_grbm_%s/*/*counter_collection.csv" % PASS[op], "GRBM_GUI_ACTIVE", prefix)
+    if not iv or not wv or op not in units_log or op not in traffic:
         continue
     frac = iv[0] / (iv[1] * 1e-9) / PEAK_WAVE_INSTS
     clk = (gr[0] / 8 / (gr[1] * 1e-9) / 1e9) if gr else float("nan")

@@ -54,7 +54,10 @@ def test_two_rank_rehearsal_line():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = check_line(r.stdout, 2, 3, 1)
     assert d["cpu_baseline"] is None
-    assert set(d["per_opcode"]) == {"box", "tri", "euclid", "angular", "mixed", "box_edge", "tri_edge", "mixed_2p20", "knn"}
+    assert set(d["per_opcode"]) == {"box", "tri", "euclid", "angular", "mixed", "box_plain", "tri_plain", "box_edge", "tri_edge",
+                                    "mixed_2p20", "mixed_2p20_plain", "knn"}
+    assert d["per_opcode"]["box"]["layout"] == "tiled" and d["per_opcode"]["box_plain"]["layout"] == "plain"
+    assert d["per_opcode"]["euclid"]["layout"] == "plain"
     assert d["per_opcode"]["mixed_2p20"]["scaling"] == "strong" and d["per_opcode"]["knn"]["leaf_major"]["scaling"] == "strong"
 
 
@@ -73,15 +76,16 @@ def test_plain_gpus_flag_starts_the_ranks_itself():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["plain", "tiled"])
 @pytest.mark.parametrize("gpus", [1, 2, 3])
-def test_sharded_mixed_stream_reassembles_to_the_whole_stream(gpus):
+def test_sharded_mixed_stream_reassembles_to_the_whole_stream(gpus, layout):
     """--only mixed --strong: one stream cut by shard.plan into one pair-aligned shard per rank; with --verify the shards'
     results, put together in rank order, are compared on rank 0 with the whole stream evaluated in one batch -- all through
     the HIP path (the ranks of this rehearsal share the one GPU)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["RT_DP_REHEARSE_ONE_GPU"] = "1"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--only", "mixed", "--strong",
-           "--strong-log2-ops", "19", "--verify"]
+           "--strong-log2-ops", "19", "--verify", "--layout", layout]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = check_line(r.stdout, gpus, 2, 1, scaling="strong")
