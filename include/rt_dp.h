@@ -435,6 +435,11 @@ int rt_dp_knn_tree_grouped_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, 
 int rt_dp_box_compact(rt_dp_ctx *ctx, const rt_dp_box_out *results, uint64_t n, const uint32_t *item, const uint32_t *children,
                       uint32_t *out_item, uint32_t *out_child, float *out_tmin, uint64_t capacity, uint64_t *count);
 
+/* The same over the tiled result buffer of a Quadbox segment (RT_DP_F_BOX_TILED: what rt_dp_launch wrote through
+ * box.tmin_out[0]).                                                                              */
+int rt_dp_box_compact_tiled(rt_dp_ctx *ctx, const void *tiled_results, uint64_t n, const uint32_t *item, const uint32_t *children,
+                            uint32_t *out_item, uint32_t *out_child, float *out_tmin, uint64_t capacity, uint64_t *count);
+
 /* The same compaction with no allocation anywhere on the call path.  It has no counterpart in the
  * reference; it exists for callers that cannot allocate device memory: code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc.  The block counts and offsets that

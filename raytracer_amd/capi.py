@@ -133,7 +133,7 @@ class KnnTree(C.Structure):
                 ("points", C.c_void_p), ("index", C.c_void_p), ("leaf_lo", C.c_void_p), ("leaf_hi", C.c_void_p)]
 
 EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize", "rt_dp_tile_pack", "rt_dp_tile_unpack",
-           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_get_option", "rt_dp_knn_euclid16", "rt_dp_knn_angular16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_box_compact", "rt_dp_box_compact_static", "rt_dp_beat_offsets_host", "rt_dp_pairs_to_beats", "rt_dp_beats_to_pairs", "rt_dp_bvh4_build_device", "rt_dp_knn_tree_build_device", "rt_dp_knn_home_leaf", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
+           "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_get_option", "rt_dp_knn_euclid16", "rt_dp_knn_angular16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_box_compact", "rt_dp_box_compact_tiled", "rt_dp_box_compact_static", "rt_dp_beat_offsets_host", "rt_dp_pairs_to_beats", "rt_dp_beats_to_pairs", "rt_dp_bvh4_build_device", "rt_dp_knn_tree_build_device", "rt_dp_knn_home_leaf", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
            "rt_dp_knn_tree_leaves", "rt_dp_knn_tree_build_host", "rt_dp_knn_home_leaf_host", "rt_dp_bvh4_max_nodes", "rt_dp_bvh4_build_host",
            "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
 
@@ -187,6 +187,7 @@ def load():
     L.rt_dp_knn_tree_build_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp]
     L.rt_dp_knn_home_leaf.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     L.rt_dp_box_compact.argtypes = [vp, C.POINTER(BoxOut), C.c_uint64, vp, vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.rt_dp_box_compact_tiled.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.rt_dp_box_compact_static.argtypes = [vp, C.POINTER(BoxOut), C.c_uint64, vp, vp, vp, vp, vp, C.c_uint64, vp, vp]
     L.rt_dp_trace_closest.argtypes = [vp, C.POINTER(Bvh4), C.POINTER(vp * 3), C.POINTER(vp * 3), C.c_uint32, C.c_float, C.c_uint32, vp, vp,
                                       C.POINTER(C.c_uint64 * 4)]
@@ -515,6 +516,15 @@ class Context:
         _check(self._L.rt_dp_box_compact_static(self._h, C.byref(ro), int(flags.shape[0]) if n is None else int(n), p(item), p(children),
                                                 p(out_item), p(out_child), p(out_tmin), int(out_item.shape[0]), p(d_count),
                                                 C.c_void_p(stream) if stream else None))
+
+    def box_compact_tiled(self, results, n, out_item, out_child, out_tmin=None, item=None, children=None):
+        """box_compact over the tiled result buffer of a RT_DP_F_BOX_TILED segment (CUDA tensor of tiled_words(n, 5) words)."""
+        assert results.is_cuda and results.is_contiguous() and results.element_size() == 4 and results.numel() >= tiled_words(n, BOX_TILE_OUT_WORDS)
+        count = C.c_uint64(0)
+        p = lambda t: None if t is None else t.data_ptr()
+        _check(self._L.rt_dp_box_compact_tiled(self._h, results.data_ptr(), int(n), p(item), p(children), p(out_item), p(out_child), p(out_tmin),
+                                               int(out_item.shape[0]), C.byref(count)))
+        return int(count.value)
 
     def pairs_to_beats(self, a, b, pair_offsets, width):
         """Vector pairs (flat float32 CUDA tensors a, b; pair_offsets: int64 numpy array [n_pairs + 1]) split into

@@ -1039,21 +1039,19 @@ int rt_dp_beats_to_pairs(rt_dp_ctx *ctx, const float *values, const uint64_t *be
     return RT_DP_OK;
 }
 
-int rt_dp_box_compact(rt_dp_ctx *ctx, const rt_dp_box_out *results, uint64_t n, const uint32_t *item, const uint32_t *children,
-                      uint32_t *out_item, uint32_t *out_child, float *out_tmin, uint64_t capacity, uint64_t *count) {
-    if (!ctx || !results || !count) return fail(RT_DP_ENULL, "rt_dp_box_compact: NULL argument");
-    *count = 0;
-    if (n == 0) return RT_DP_OK;
+static int box_compact(const char *who, rt_dp_ctx *ctx, const uint32_t *flags, const float *const tm[4], uint32_t tile_words, uint64_t n,
+                       const uint32_t *item, const uint32_t *children, uint32_t *out_item, uint32_t *out_child, float *out_tmin,
+                       uint64_t capacity, uint64_t *count) {
     if (n > kMaxOps) return fail(RT_DP_EINVAL, "n = %llu is not representable (limit 2^40)", (unsigned long long)n);
-    if (!results->flags || (capacity && (!out_item || !out_child))) return fail(RT_DP_ENULL, "rt_dp_box_compact: NULL array");
-    uintptr_t acc = reinterpret_cast<uintptr_t>(results->flags) | reinterpret_cast<uintptr_t>(item) | reinterpret_cast<uintptr_t>(children) |
+    if (!flags || (capacity && (!out_item || !out_child))) return fail(RT_DP_ENULL, "%s: NULL array", who);
+    uintptr_t acc = reinterpret_cast<uintptr_t>(flags) | reinterpret_cast<uintptr_t>(item) | reinterpret_cast<uintptr_t>(children) |
                     reinterpret_cast<uintptr_t>(out_item) | reinterpret_cast<uintptr_t>(out_child) | reinterpret_cast<uintptr_t>(out_tmin);
     if (out_tmin)
         for (int k = 0; k < 4; ++k) {
-            if (!results->tmin_out[k]) return fail(RT_DP_ENULL, "rt_dp_box_compact: out_tmin needs all four tmin_out arrays");
-            acc |= reinterpret_cast<uintptr_t>(results->tmin_out[k]);
+            if (!tm[k]) return fail(RT_DP_ENULL, "%s: out_tmin needs all four tmin_out arrays", who);
+            acc |= reinterpret_cast<uintptr_t>(tm[k]);
         }
-    if (acc & 3u) return fail(RT_DP_EALIGN, "rt_dp_box_compact: arrays must be 4-byte aligned");
+    if (acc & 3u) return fail(RT_DP_EALIGN, "%s: arrays must be 4-byte aligned", who);
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
     hipStream_t s = ctx->stream;
@@ -1065,13 +1063,34 @@ int rt_dp_box_compact(rt_dp_ctx *ctx, const rt_dp_box_out *results, uint64_t n, 
     uint32_t *blockcnt = reinterpret_cast<uint32_t *>(ctx->d_trace + o_cnt);
     unsigned long long *offsets64 = reinterpret_cast<unsigned long long *>(ctx->d_trace + o_off);
     unsigned long long *total = reinterpret_cast<unsigned long long *>(ctx->d_trace + o_tot);
-    const float *tm[4] = {results->tmin_out[0], results->tmin_out[1], results->tmin_out[2], results->tmin_out[3]};
-    HIP_TRY(compact_hits(results->flags, tm, n, item, children, blockcnt, offsets64, total, capacity, out_item, out_child, out_tmin, s));
+    HIP_TRY(compact_hits(flags, tm, n, item, children, blockcnt, offsets64, total, capacity, out_item, out_child, out_tmin, s, tile_words));
     unsigned long long h = 0;
     HIP_TRY(hipMemcpyAsync(&h, total, sizeof h, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     *count = h;
     return RT_DP_OK;
+}
+
+int rt_dp_box_compact(rt_dp_ctx *ctx, const rt_dp_box_out *results, uint64_t n, const uint32_t *item, const uint32_t *children,
+                      uint32_t *out_item, uint32_t *out_child, float *out_tmin, uint64_t capacity, uint64_t *count) {
+    if (!ctx || !results || !count) return fail(RT_DP_ENULL, "rt_dp_box_compact: NULL argument");
+    *count = 0;
+    if (n == 0) return RT_DP_OK;
+    const float *tm[4] = {results->tmin_out[0], results->tmin_out[1], results->tmin_out[2], results->tmin_out[3]};
+    return box_compact("rt_dp_box_compact", ctx, results->flags, tm, 0u, n, item, children, out_item, out_child, out_tmin, capacity, count);
+}
+
+int rt_dp_box_compact_tiled(rt_dp_ctx *ctx, const void *tiled_results, uint64_t n, const uint32_t *item, const uint32_t *children,
+                            uint32_t *out_item, uint32_t *out_child, float *out_tmin, uint64_t capacity, uint64_t *count) {
+    if (!ctx || !count) return fail(RT_DP_ENULL, "rt_dp_box_compact_tiled: NULL argument");
+    *count = 0;
+    if (n == 0) return RT_DP_OK;
+    if (!tiled_results) return fail(RT_DP_ENULL, "rt_dp_box_compact_tiled: the result buffer is NULL");
+    const uint32_t *words = static_cast<const uint32_t *>(tiled_results);   // word k of tile 0 starts at k * RT_DP_TILE_OPS
+    const float *tm[4];
+    for (int k = 0; k < 4; ++k) tm[k] = reinterpret_cast<const float *>(words + (size_t)k * kTileOps);
+    return box_compact("rt_dp_box_compact_tiled", ctx, words + (size_t)4 * kTileOps, tm, (uint32_t)kBoxOutWords, n, item, children, out_item, out_child,
+                       out_tmin, capacity, count);
 }
 
 // rt_dp_box_compact for callers that cannot allocate: offsets in a file-scope device array (compact.hip), the

@@ -17,10 +17,16 @@ namespace rtdp {
 
 constexpr int kCmpBlk = 256;
 
-__global__ __launch_bounds__(kCmpBlk) void k_compact_count(const uint32_t *__restrict__ flags, uint64_t n, uint32_t *__restrict__ blockcnt) {
+// Where the result words of op i sit: plain arrays (tile_words 0), or a tiled result buffer of tile_words words per op
+// whose word k is addressed through a pointer to that word's run in tile 0.
+__device__ __forceinline__ uint64_t result_index(uint64_t i, uint32_t tile_words) {
+    return tile_words ? (i / kTileOps) * (uint64_t)tile_words * kTileOps + (i % kTileOps) : i;
+}
+
+__global__ __launch_bounds__(kCmpBlk) void k_compact_count(const uint32_t *__restrict__ flags, uint64_t n, uint32_t *__restrict__ blockcnt, uint32_t tile_words) {
     __shared__ uint32_t s_w[kCmpBlk / 64];
     const uint64_t i = (uint64_t)blockIdx.x * kCmpBlk + threadIdx.x;
-    uint32_t c = (i < n) ? (uint32_t)__popc(flags[i] & 15u) : 0u;
+    uint32_t c = (i < n) ? (uint32_t)__popc(flags[result_index(i, tile_words)] & 15u) : 0u;
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
     __syncthreads();
@@ -53,11 +59,12 @@ __global__ __launch_bounds__(kCmpBlk) void k_compact_emit(const uint32_t *__rest
                                                          const uint32_t *__restrict__ item, const uint32_t *__restrict__ children,
                                                          const unsigned long long *__restrict__ offsets64, uint64_t capacity,
                                                          uint32_t *__restrict__ out_item, uint32_t *__restrict__ out_child,
-                                                         float *__restrict__ out_tmin) {
+                                                         float *__restrict__ out_tmin, uint32_t tile_words) {
     __shared__ uint32_t s_w[kCmpBlk / 64];
     const uint64_t i = (uint64_t)blockIdx.x * kCmpBlk + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t fl = (i < n) ? flags[i] : 0u;
+    const uint64_t ri = result_index(i, tile_words);
+    const uint32_t fl = (i < n) ? flags[ri] : 0u;
     const uint32_t cnt = (uint32_t)__popc(fl & 15u);  // hits come first: they sit in slots 0 .. cnt - 1
     const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t off = 0, tot = 0;
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(kCmpBlk) void k_compact_emit(const uint32_t *__rest
     for (int w = 0; w < wave; ++w) base += s_w[w];
     if (cnt == 0) return;
     const uint32_t it = item ? item[i] : (uint32_t)i;
-    const float t[4] = {out_tmin ? t0[i] : 0.0f, out_tmin ? t1[i] : 0.0f, out_tmin ? t2[i] : 0.0f, out_tmin ? t3[i] : 0.0f};
+    const float t[4] = {out_tmin ? t0[ri] : 0.0f, out_tmin ? t1[ri] : 0.0f, out_tmin ? t2[ri] : 0.0f, out_tmin ? t3[ri] : 0.0f};
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
         if (k >= cnt) break;
@@ -88,13 +95,13 @@ __global__ __launch_bounds__(kCmpBlk) void k_compact_emit(const uint32_t *__rest
 
 hipError_t compact_hits(const uint32_t *flags, const float *const tmin[4], uint64_t n, const uint32_t *item, const uint32_t *children,
                         uint32_t *blockcnt, unsigned long long *offsets64, unsigned long long *total, uint64_t capacity, uint32_t *out_item,
-                        uint32_t *out_child, float *out_tmin, hipStream_t s) {
+                        uint32_t *out_child, float *out_tmin, hipStream_t s, uint32_t tile_words) {
     const uint64_t nblk = (n + kCmpBlk - 1) / kCmpBlk;
     if (nblk > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_compact_count, dim3((unsigned)nblk), dim3(kCmpBlk), 0, s, flags, n, blockcnt);
+    hipLaunchKernelGGL(k_compact_count, dim3((unsigned)nblk), dim3(kCmpBlk), 0, s, flags, n, blockcnt, tile_words);
     hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, s, blockcnt, (uint32_t)nblk, total, offsets64);
     hipLaunchKernelGGL(k_compact_emit, dim3((unsigned)nblk), dim3(kCmpBlk), 0, s, flags, tmin[0], tmin[1], tmin[2], tmin[3], n, item,
-                       children, offsets64, capacity, out_item, out_child, out_tmin);
+                       children, offsets64, capacity, out_item, out_child, out_tmin, tile_words);
     return hipGetLastError();
 }
 
@@ -138,7 +145,7 @@ hipError_t compact_hits_static(int device, const uint32_t *flags, const float *c
     if (!base) return hipErrorNotInitialized;
     unsigned long long *offsets64 = reinterpret_cast<unsigned long long *>(base);
     uint32_t *blockcnt = reinterpret_cast<uint32_t *>(base + kStaticBlocks * 8);
-    return compact_hits(flags, tmin, n, item, children, blockcnt, offsets64, d_count, capacity, out_item, out_child, out_tmin, s);
+    return compact_hits(flags, tmin, n, item, children, blockcnt, offsets64, d_count, capacity, out_item, out_child, out_tmin, s, 0u);
 }
 
 }  // namespace rtdp

@@ -107,10 +107,11 @@ hipError_t stream_fused_eval(const uint32_t *in, uint64_t n, uint64_t capacity, 
                              StreamSideView *view, hipStream_t s);
 hipError_t stream_fused_fold(const StreamSideView &v, uint64_t n, const float *state_in, float *state_out, uint32_t *out, hipStream_t s);
 
-// hit-mask compaction behind a Quadbox batch (compact.hip); blockcnt [ceil(n/256)] u32, offsets64 likewise u64, total one u64
+// hit-mask compaction behind a Quadbox batch (compact.hip); blockcnt [ceil(n/256)] u32, offsets64 likewise u64, total one u64.
+// tile_words 0: flags / tmin are plain arrays; kBoxOutWords: they point at their word's run in tile 0 of a tiled result buffer
 hipError_t compact_hits(const uint32_t *flags, const float *const tmin[4], uint64_t n, const uint32_t *item, const uint32_t *children,
                         uint32_t *blockcnt, unsigned long long *offsets64, unsigned long long *total, uint64_t capacity, uint32_t *out_item,
-                        uint32_t *out_child, float *out_tmin, hipStream_t s);
+                        uint32_t *out_child, float *out_tmin, hipStream_t s, uint32_t tile_words = 0);
 
 // the same with the offsets in a file-scope device array (no allocation on the call path): compact_static_init once per
 // device with that device current, then compact_hits_static; *d_count (device memory) receives the number of entries

@@ -17,6 +17,21 @@ pytestmark = pytest.mark.gpu
 N = 1 << 24
 
 
+def _tiled_results(ctx, torch, arrays, n, words_out, derive=False, tri=False):
+    """The same ops through the tiled layout: packed on the device, evaluated, unpacked into plain int32 arrays."""
+    operands = torch.empty(capi.tiled_words(n, len(arrays)), dtype=torch.int32, device="cuda")
+    results = torch.empty(capi.tiled_words(n, words_out), dtype=torch.int32, device="cuda")
+    out = [torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(words_out)]
+    b = capi.Batch()
+    (b.set_tri_tiled if tri else b.set_box_tiled)(operands, results, n)
+    torch.cuda.synchronize()
+    ctx.tile_pack(arrays, operands, n)
+    ctx.launch(b)
+    ctx.tile_unpack(results, out, n)
+    ctx.synchronize()
+    return out
+
+
 def _box_batch(torch, fields, n):
     tm = torch.empty(4, n, dtype=torch.float32, device="cuda")
     flags = torch.empty(n, dtype=torch.int32, device="cuda")
@@ -154,7 +169,12 @@ def test_edge_class_streams_2p24_against_oracle(ctx, oracle, torch_cuda):
         assert_bits_equal(tm[k].cpu().numpy(), wt[k], "tmin_out[%d]" % k)
     assert_bits_equal(flags.cpu().numpy(), wf, "flags")
     assert not bool(torch.isnan(tm).any())                       # a NaN never reaches tmin_out (a hit needs tmin < tmax)
-    del fields, b, tm, flags
+    # the tiled layout gives the same bits, all 2^24 ops with their edge classes
+    tiled = _tiled_results(ctx, torch, fields, N, 5)
+    for k in range(4):
+        assert bool((tiled[k] == tm[k].view(torch.int32)).all()), "tiled tmin_out[%d]" % k
+    assert bool((tiled[4] == flags).all()), "tiled flags"
+    del fields, b, tm, flags, tiled
 
     tf, k = synth.tri_stream(N, 20241009, "cuda", 0.01)
     assert 0.008 < float((((k >> 4) & 3) == 3).float().mean()) < 0.02          # kz encoded as 3
@@ -172,6 +192,8 @@ def test_edge_class_streams_2p24_against_oracle(ctx, oracle, torch_cuda):
     assert not bool(((td == 0) & (hit == 1)).any())
     nan_out = torch.isnan(tn) | torch.isnan(td)
     assert int(nan_out.sum()) > 1000 and bool((tn.view(torch.int32)[torch.isnan(tn)] == 0x7FC00000).all())   # canonical NaN
+    tiled = _tiled_results(ctx, torch, list(tf) + [k], N, 3, tri=True)
+    assert bool((tiled[0] == tn.view(torch.int32)).all()) and bool((tiled[1] == td.view(torch.int32)).all()) and bool((tiled[2] == hit).all())
 
 
 def _windows(n, rng, count=64, size=1 << 16, ends=1 << 20):

@@ -270,3 +270,41 @@ def test_tiled_argument_errors(ctx, torch_cuda):
     ptrs[1] = None
     assert L.rt_dp_tile_pack(ctx._h, ptrs, 2, n, results.data_ptr(), None) == capi.ENULL
     assert L.rt_dp_tile_pack(ctx._h, ptrs, 2, 0, None, None) == capi.OK        # nothing to do
+
+
+@pytest.mark.parametrize("n", [1, 257, T - 1, T + 1, 70001])
+@pytest.mark.parametrize("tables", [False, True])
+def test_compaction_over_a_tiled_result_buffer(ctx, oracle, torch_cuda, n, tables):
+    """rt_dp_box_compact_tiled: the visit list read off the oracle's results (ops in order, hits closest first), from
+    the buffer the tiled box kernel wrote."""
+    torch = torch_cuda
+    from test_box_compact import model
+    from test_gpu_canaries import Guarded
+    g = Guarded(torch)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    fields = [np.ascontiguousarray(f) for f in gen.box_ops(n, seed=100 + n)]
+    ref_t, ref_fl = oracle.box_soa(fields)
+    ref_fl = np.asarray(ref_fl).view(u32)
+    rng = np.random.default_rng(n)
+    item = rng.integers(0, 2 ** 32, n, dtype=np.uint32) if tables else None
+    children = rng.integers(0, 2 ** 32, (n, 4), dtype=np.uint32) if tables else None
+    want_i, want_c, want_t = model(ref_t, ref_fl, item, children, tables)
+    operands = dev(pack_numpy(fields).view(np.int32))
+    results = torch.full((capi.tiled_words(n, 5),), SENTINEL, dtype=torch.int32, device="cuda")
+    b = capi.Batch()
+    b.set_box_tiled(operands, results, n)
+    torch.cuda.synchronize()
+    ctx.eval(b)
+    cap = max(1, want_i.shape[0])
+    oi, oc = g.empty((cap,), torch.int32), g.empty((cap,), torch.int32)
+    ot = g.empty((cap,), torch.float32) if tables else None
+    torch.cuda.synchronize()
+    count = ctx.box_compact_tiled(results, n, oi, oc, ot, None if item is None else dev(item.view(np.int32)),
+                                  None if children is None else dev(children.view(np.int32)))
+    torch.cuda.synchronize()
+    g.check()
+    assert count == want_i.shape[0]
+    assert np.array_equal(oi.cpu().numpy().view(u32)[:count], want_i)
+    assert np.array_equal(oc.cpu().numpy().view(u32)[:count], want_c)
+    if tables:
+        assert np.array_equal(ot.cpu().numpy().view(u32)[:count], want_t.view(u32))
