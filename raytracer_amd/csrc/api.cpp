@@ -46,9 +46,13 @@ struct rt_dp_ctx {
     hipStream_t stream = nullptr;
     // accumulator registers live in HBM; two copies so that the workgroup that
     // reads the incoming value never races the one that writes the outgoing one
-    float *d_state = nullptr;  // [3][4]: {euclid, dot, norm, pad}; copies 0 / 1 alternate, copy 2 is a call's backup
-    bool state_pinned = false;  // a captured graph holds the address of copy `cur`: the registers stay there from then on
-    int cur = 0;               // which copy is current
+    // The accumulator registers, [3][4] floats: {euclid, dot, norm, pad}; copy 2 is a call's backup.  A beat kernel reads its
+    // opcode's register(s) from one of the copies 0 / 1 and leaves the new value in the other, so the reader of a launch never
+    // races its writer; which copy is current is kept per opcode (a batch without beats of an opcode leaves that opcode's
+    // register where it is, and nothing has to be copied to carry it along).
+    float *d_state = nullptr;
+    int cur_e = 0, cur_a = 0;                  // current copy of the Euclidean register / of the two angular registers
+    bool pinned_e = false, pinned_a = false;   // a captured graph holds the address of that copy: the register stays there from then on
     // grow-only staging for host-pointer batches
     char *d_stage = nullptr;
     size_t stage_bytes = 0;
@@ -227,12 +231,12 @@ bool is_capturing(hipStream_t s) {
     return cap != hipStreamCaptureStatusNone;
 }
 
-// The kernels of a batch read the registers from copy `cur` and left the new ones in the other copy: make that
-// the current one.  Normally the two copies just swap roles; once a graph has captured their addresses the new
-// values are copied back instead, so that replays and direct launches keep finding the registers in one place.
-int commit_state(rt_dp_ctx *ctx, hipStream_t s) {
-    if (!ctx->state_pinned) { ctx->cur ^= 1; return RT_DP_OK; }
-    HIP_TRY(hipMemcpyAsync(ctx->d_state + 4 * ctx->cur, ctx->d_state + 4 * (ctx->cur ^ 1), 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
+// A beat kernel read its opcode's register(s) (`words` floats at `slot`) from copy `cur` and left the new ones in the other
+// copy: make that the current one.  Normally the two copies just swap roles; once a graph has captured their addresses the
+// new values are copied back instead, so that replays and direct launches keep finding the register in one place.
+int commit_state(rt_dp_ctx *ctx, int &cur, bool pinned, int slot, int words, hipStream_t s) {
+    if (!pinned) { cur ^= 1; return RT_DP_OK; }
+    HIP_TRY(hipMemcpyAsync(ctx->d_state + 4 * cur + slot, ctx->d_state + 4 * (cur ^ 1) + slot, words * sizeof(float), hipMemcpyDeviceToDevice, s));
     return RT_DP_OK;
 }
 
@@ -271,24 +275,25 @@ int launch_device(rt_dp_ctx *ctx, const rt_dp_op_batch *in, const rt_dp_result_b
         // captured kernels are the ones that own whole pairs and need no workspace; and the registers stay at the
         // address the graph holds.
         const bool captured = is_capturing(s);
-        if (captured) ctx->state_pinned = true;
-        float *cur = ctx->d_state + 4 * ctx->cur, *nxt = ctx->d_state + 4 * (ctx->cur ^ 1);
-        // registers of an opcode without beats in this batch are carried over unchanged
-        HIP_TRY(hipMemcpyAsync(nxt, cur, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (n_euc) {
-            VecArgs a{in->euc.a, in->euc.b, in->euc.ctl, out->euc.accumulator, nullptr, cur + 0, nxt + 0};
+            if (captured) ctx->pinned_e = true;
+            VecArgs a{in->euc.a, in->euc.b, in->euc.ctl, out->euc.accumulator, nullptr, ctx->d_state + 4 * ctx->cur_e, ctx->d_state + 4 * (ctx->cur_e ^ 1)};
             int rc = captured ? RT_DP_OK : chain_for(ctx, n_euc, s, a);
             if (rc != RT_DP_OK) return rc;
             HIP_TRY(launch_euclid(a, n_euc, ctx->tuning, s));
+            rc = commit_state(ctx, ctx->cur_e, ctx->pinned_e, 0, 1, s);
+            if (rc != RT_DP_OK) return rc;
         }
         if (n_ang) {
-            VecArgs a{in->ang.a, in->ang.b, in->ang.ctl, out->ang.dot_product, out->ang.norm, cur + 1, nxt + 1};
+            if (captured) ctx->pinned_a = true;
+            VecArgs a{in->ang.a, in->ang.b, in->ang.ctl, out->ang.dot_product, out->ang.norm, ctx->d_state + 4 * ctx->cur_a + 1,
+                      ctx->d_state + 4 * (ctx->cur_a ^ 1) + 1};
             int rc = captured ? RT_DP_OK : chain_for(ctx, n_ang, s, a);
             if (rc != RT_DP_OK) return rc;
             HIP_TRY(launch_angular(a, n_ang, ctx->tuning, s));
+            rc = commit_state(ctx, ctx->cur_a, ctx->pinned_a, 1, 2, s);
+            if (rc != RT_DP_OK) return rc;
         }
-        int rc = commit_state(ctx, s);
-        if (rc != RT_DP_OK) return rc;
     }
     return RT_DP_OK;
 }
@@ -610,7 +615,11 @@ int rt_dp_get_accum(rt_dp_ctx *ctx, float acc[3]) {
     int rc = join_caller_stream(ctx, true);
     if (rc != RT_DP_OK) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipMemcpy(acc, ctx->d_state + 4 * ctx->cur, 3 * sizeof(float), hipMemcpyDeviceToHost));
+    float h[8];
+    HIP_TRY(hipMemcpy(h, ctx->d_state, sizeof h, hipMemcpyDeviceToHost));
+    acc[0] = h[4 * ctx->cur_e];
+    acc[1] = h[4 * ctx->cur_a + 1];
+    acc[2] = h[4 * ctx->cur_a + 2];
     return RT_DP_OK;
 }
 
@@ -620,8 +629,8 @@ int rt_dp_set_accum(rt_dp_ctx *ctx, const float acc[3]) {
     int rc = join_caller_stream(ctx, true);
     if (rc != RT_DP_OK) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    const float v[4] = {acc[0], acc[1], acc[2], 0.0f};
-    HIP_TRY(hipMemcpy(ctx->d_state + 4 * ctx->cur, v, sizeof v, hipMemcpyHostToDevice));
+    const float v[8] = {acc[0], acc[1], acc[2], 0.0f, acc[0], acc[1], acc[2], 0.0f};  // both copies: whichever is current per opcode
+    HIP_TRY(hipMemcpy(ctx->d_state, v, sizeof v, hipMemcpyHostToDevice));
     return RT_DP_OK;
 }
 
@@ -671,29 +680,39 @@ int rt_dp_eval_bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt
         StreamSideView view;
         const uint32_t *in_words = reinterpret_cast<const uint32_t *>(d_in);
         uint32_t *out_words = reinterpret_cast<uint32_t *>(d_out);
-        const int cur0 = ctx->cur;
-        HIP_TRY(hipMemcpyAsync(ctx->d_state + 8, ctx->d_state + 4 * cur0, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));  // backup
+        // the fold kernel takes all three registers from one copy: bring the Euclidean one over to the angular ones' copy first
+        const int home_e = ctx->cur_e, home_a = ctx->cur_a;
+        if (ctx->extended && home_e != home_a)
+            HIP_TRY(hipMemcpyAsync(ctx->d_state + 4 * home_a, ctx->d_state + 4 * home_e, sizeof(float), hipMemcpyDeviceToDevice, s));
+        int c = home_a;
+        HIP_TRY(hipMemcpyAsync(ctx->d_state + 8, ctx->d_state + 4 * c, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));  // backup
         HIP_TRY(stream_fused_begin(ctx->d_stream, first, s));
         for (uint64_t off = 0; off < n; off += chunk) {
             const uint64_t m = (n - off < chunk) ? (n - off) : chunk;
             HIP_TRY(stream_fused_eval(in_words + off * 84, m, first, ctx->extended ? 1 : 0, out_words + off * 21, ctx->d_stream, &view, s));
             if (ctx->extended) {
-                float *cur = ctx->d_state + 4 * ctx->cur, *nxt = ctx->d_state + 4 * (ctx->cur ^ 1);
+                float *cur = ctx->d_state + 4 * c, *nxt = ctx->d_state + 4 * (c ^ 1);
                 // registers of an opcode without beats in this piece are carried over unchanged
                 HIP_TRY(hipMemcpyAsync(nxt, cur, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
                 HIP_TRY(stream_fused_fold(view, m, cur, nxt, out_words + off * 21, s));
-                rc = commit_state(ctx, s);
-                if (rc != RT_DP_OK) return rc;
+                c ^= 1;
             }
         }
         uint32_t bad = 0;
         HIP_TRY(hipMemcpyAsync(&bad, view.flags + 8, sizeof bad, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (bad) {  // the registers keep their values from before the call
-            ctx->cur = cur0;
-            HIP_TRY(hipMemcpy(ctx->d_state + 4 * cur0, ctx->d_state + 8, 4 * sizeof(float), hipMemcpyDeviceToDevice));
-            return fail(RT_DP_EOPCODE, "the record stream holds an opcode > 3; the RTL's opcode field is 2 bits wide");
+            c = home_a;
+            HIP_TRY(hipMemcpy(ctx->d_state + 4 * c, ctx->d_state + 8, 4 * sizeof(float), hipMemcpyDeviceToDevice));
         }
+        if (ctx->extended) {
+            // all three registers are in copy c now; a register whose address a graph holds goes back to that address
+            if (ctx->pinned_e && c != home_e) HIP_TRY(hipMemcpy(ctx->d_state + 4 * home_e, ctx->d_state + 4 * c, sizeof(float), hipMemcpyDeviceToDevice));
+            if (!ctx->pinned_e) ctx->cur_e = c;
+            if (ctx->pinned_a && c != home_a) HIP_TRY(hipMemcpy(ctx->d_state + 4 * home_a + 1, ctx->d_state + 4 * c + 1, 2 * sizeof(float), hipMemcpyDeviceToDevice));
+            if (!ctx->pinned_a) ctx->cur_a = c;
+        }
+        if (bad) return fail(RT_DP_EOPCODE, "the record stream holds an opcode > 3; the RTL's opcode field is 2 bits wide");
         return RT_DP_OK;
     }
     const uint64_t nblk = (n + 255) / 256;

@@ -207,3 +207,63 @@ def test_a_batch_captured_into_a_graph_replays_with_new_operands_and_carries_the
     graph.replay()
     torch.cuda.synchronize()
     check(0, "replay after a direct launch")
+
+
+def test_registers_of_an_opcode_survive_batches_without_it(ctx, oracle, torch_cuda):
+    """The Euclidean and the angular registers are kept in alternating device copies per opcode: batches with beats of one
+    opcode, of the other, of both, and a record stream through rt_dp_eval_bundles_device in between must each continue
+    from where the opcode's previous beats stopped."""
+    torch = torch_cuda
+    from test_gpu_parity import _mixed_stream
+
+    def beats(width, seed, pairs=40):
+        a, b, ctl, _ = gen.vec_beats(pairs, width, seed=seed)
+        ctl = ctl.copy()
+        ctl[-1] &= u32(0xFFFF)          # stops inside a pair: the register stays live
+        return a, b, ctl
+
+    state = {"e": f32(0), "d": f32(0), "n": f32(0)}
+
+    def run(kind, seed):
+        b = capi.Batch()
+        outs = {}
+        if "e" in kind:
+            a, bb, ctl = beats(16, seed)
+            outs["e"] = (np.zeros(ctl.shape[0], f32), a, bb, ctl)
+            b.set_euclid(a, bb, ctl, outs["e"][0])
+        if "a" in kind:
+            q, c, ctl8 = beats(8, seed + 1)
+            outs["a"] = (np.zeros(ctl8.shape[0], f32), np.zeros(ctl8.shape[0], f32), q, c, ctl8)
+            b.set_angular(q, c, ctl8, outs["a"][0], outs["a"][1])
+        ctx.eval(b)
+        if "e" in outs:
+            got, a, bb, ctl = outs["e"]
+            want, state["e"] = oracle.euclid_beats(a, bb, ctl, state["e"])
+            assert_bits_equal(got, want, "euclidean beats of batch %r" % kind)
+        if "a" in outs:
+            gd, gn, q, c, ctl8 = outs["a"]
+            wd, wn, state["d"], state["n"] = oracle.angular_beats(q, c, ctl8, state["d"], state["n"])
+            assert_bits_equal(gd, wd, "angular dot of batch %r" % kind)
+            assert_bits_equal(gn, wn, "angular norm of batch %r" % kind)
+        assert_bits_equal(ctx.get_accum(), np.array([state["e"], state["d"], state["n"]], f32), "registers after batch %r" % kind)
+
+    ctx.reset()
+    for step, kind in enumerate(["e", "a", "e", "e", "ea", "a", "a", "e"]):
+        run(kind, 500 + 10 * step)
+    # a record stream in HBM (the fused path folds all three registers in one kernel), then single opcodes again
+    stream = _mixed_stream(7, 50, 50, 12, 12)
+    stream[np.nonzero(stream[:, 0] == 2)[0][-1], 83] = 0      # both distance opcodes stop inside a pair
+    stream[np.nonzero(stream[:, 0] == 3)[0][-1], 83] = 0
+    d_in = torch.from_numpy(stream.view(np.int32)).cuda()
+    d_out = torch.empty((stream.shape[0], 21), dtype=torch.int32, device="cuda")
+    ctx.eval_bundles_device(d_in, d_out)
+    c2 = capi.Context()
+    c2.set_accum([state["e"], state["d"], state["n"]])
+    want = c2.eval_bundles(stream)                             # host-partitioned path of a second context from the same registers
+    assert_bits_equal(d_out.cpu().numpy().view(u32), want, "record stream continuing the registers")
+    after = c2.get_accum()
+    c2.close()
+    assert_bits_equal(ctx.get_accum(), after, "registers after the record stream")
+    state["e"], state["d"], state["n"] = after
+    for step, kind in enumerate(["a", "e", "ea"]):
+        run(kind, 700 + 10 * step)
