@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM-peak fraction of every op kernel against the batch size (the table in DESIGN.md): bash scripts/size_table.sh
+# HBM-peak fraction of every op kernel against the batch size: bash scripts/size_table.sh
 # box / tri in both layouts (tiled: one buffer per segment; plain: one array per operand)
 mkdir -p gpurun_out; OUT=gpurun_out/size_table.txt; : > $OUT
 for spec in "box tiled" "box plain" "tri tiled" "tri plain" "euclid plain" "angular plain"; do
