@@ -194,6 +194,44 @@ __global__ __launch_bounds__(256) void k_tiled_x(const float *__restrict__ in, u
     __builtin_nontemporal_store(fl, q + 4 * T);
 }
 
+// tile stride (words per op slot in the buffer) as a parameter: WIN words per op are read, SIN words are reserved per tile
+template <int T, int SIN, int SOUT>
+__global__ __launch_bounds__(256) void k_tri_stride(const float *__restrict__ in, uint32_t *__restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t tile = i / T, w = i % T;
+    const float *p = in + tile * (uint64_t)(SIN * T) + w;
+    float x[kTriFields];
+#pragma unroll
+    for (int f = 0; f < kTriFields; ++f) x[f] = __builtin_nontemporal_load(p + f * T);
+    const uint32_t kk = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p + 15 * T)) & 0x3Fu;
+    float tn, td; uint32_t h;
+    tri_one(x, kk, tn, td, h);
+    uint32_t *q = out + tile * (uint64_t)(SOUT * T) + w;
+    __builtin_nontemporal_store(__float_as_uint(tn), q);
+    __builtin_nontemporal_store(__float_as_uint(td), q + T);
+    __builtin_nontemporal_store(h, q + 2 * T);
+}
+template <int T, int SIN, int SOUT>
+__global__ __launch_bounds__(256) void k_box_stride(const float *__restrict__ in, uint32_t *__restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t tile = i / T, w = i % T;
+    const float *p = in + tile * (uint64_t)(SIN * T) + w;
+    float x[kBoxFields];
+#pragma unroll
+    for (int f = 0; f < kBoxFields; ++f) {
+        x[f] = __builtin_nontemporal_load(p + f * T);
+        asm volatile("s_nop 5");
+    }
+    float t[4]; uint32_t fl;
+    box_one(x, t, fl);
+    uint32_t *q = out + tile * (uint64_t)(SOUT * T) + w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(__float_as_uint(t[k]), q + k * T);
+    __builtin_nontemporal_store(fl, q + 4 * T);
+}
+
 struct Ptrs { const float *in[kBoxFields]; uint32_t *out[5]; };
 __global__ __launch_bounds__(256) void k_plain(Ptrs a, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
@@ -289,22 +327,33 @@ int main(int argc, char **argv) {
         hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, in, padded * kBoxFields, 12345u);
         CK(hipDeviceSynchronize());
         const unsigned blocks = (unsigned)((n + 255) / 256);
-        const int caps[] = {3, 4};
+        const int caps[] = {3};
         for (int round = 0; round < 2; ++round)
         for (int w : caps) {
             const unsigned lds = lds_for(w);
             double ms;
 #define BOXRUN(NAME, K) ms = time_ms([&] { hipLaunchKernelGGL(K, dim3(blocks), dim3(256), lds, 0, in, out, n); }, 10, 40); \
             printf("box n 2^%d cap %2d  %-20s %.4f ms frac %.4f\n", lg, w, NAME, ms, n * 156.0 / ms / 1e6 / 8000.0);
-            Ptrs a; for (int f = 0; f < kBoxFields; ++f) a.in[f] = in + f * n; for (int k = 0; k < 5; ++k) a.out[k] = out + k * n;
-#define PLRUN(NAME, K) ms = time_ms([&] { hipLaunchKernelGGL(K, dim3(blocks), dim3(256), lds, 0, a, n); }, 10, 40); \
-            printf("box n 2^%d cap %2d  %-20s %.4f ms frac %.4f\n", lg, w, NAME, ms, n * 156.0 / ms / 1e6 / 8000.0);
-            PLRUN("plain pace 0", (k_plain_p<0>))
-            PLRUN("plain pace 2", (k_plain_p<2>))
-            PLRUN("plain pace 6", (k_plain_p<6>))
-            PLRUN("plain pace 10", (k_plain_p<10>))
-            PLRUN("plain pace 16", (k_plain_p<16>))
-            BOXRUN("tiled pace 6", (k_tiled_vp<8192, 6>))
+            {
+                float *in2; uint32_t *out2;   // room for 40 words in and 8 words out per op
+                CK(hipMalloc(&in2, (n + 8192) * 40 * 4)); CK(hipMalloc(&out2, (n + 8192) * 8 * 4));
+                hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, in2, (n + 8192) * 40, 777u);
+                CK(hipDeviceSynchronize());
+#define SRUN(NAME, K, BYTES) ms = time_ms([&] { hipLaunchKernelGGL(K, dim3(blocks), dim3(256), lds, 0, in2, out2, n); }, 10, 40); \
+                printf("n 2^%d cap %2d  %-28s %.4f ms frac %.4f\n", lg, w, NAME, ms, n * BYTES / ms / 1e6 / 8000.0);
+                SRUN("tri stride 16 / 3", (k_tri_stride<8192, 16, 3>), 76.0)
+                SRUN("tri stride 17 / 3", (k_tri_stride<8192, 17, 3>), 76.0)
+                SRUN("tri stride 18 / 3", (k_tri_stride<8192, 18, 3>), 76.0)
+                SRUN("tri stride 20 / 3", (k_tri_stride<8192, 20, 3>), 76.0)
+                SRUN("tri stride 16 / 4", (k_tri_stride<8192, 16, 4>), 76.0)
+                SRUN("tri stride 17 / 4", (k_tri_stride<8192, 17, 4>), 76.0)
+                SRUN("tri stride 19 / 5", (k_tri_stride<8192, 19, 5>), 76.0)
+                SRUN("box stride 34 / 5", (k_box_stride<8192, 34, 5>), 156.0)
+                SRUN("box stride 35 / 5", (k_box_stride<8192, 35, 5>), 156.0)
+                SRUN("box stride 36 / 6", (k_box_stride<8192, 36, 6>), 156.0)
+                SRUN("box stride 32+8 / 8", (k_box_stride<8192, 40, 8>), 156.0)
+                CK(hipFree(in2)); CK(hipFree(out2));
+            }
             fflush(stdout);
         }
         CK(hipFree(in)); CK(hipFree(out));
