@@ -124,8 +124,8 @@ def parse():
     p.add_argument("--verify", action="store_true", help="sharded mixed stream: also evaluate the whole stream on rank 0 and compare it with the "
                                                          "shards' results put together (small sizes only: results travel through host memory)")
     a = p.parse_args()
-    if a.stagger_kib:
-        a.layout = "plain"      # the spacing of the operand arrays is a property of the plain layout only
+    if a.stagger_kib or a.sweep or a.launch_ops:
+        a.layout = "plain"      # array spacing, ops per lane and partial launches are properties of the plain layout only
     return a
 
 
