@@ -89,3 +89,20 @@ def hip_angular(ctx, q, c, ctl, device=False, torch=None):
     bt.set_angular(np.ascontiguousarray(q, f32), np.ascontiguousarray(c, f32), np.ascontiguousarray(ctl, u32), dot, norm, n)
     ctx.eval(bt)
     return dot, norm
+
+
+def hip_tiled(ctx, arrays, n, words_out, tri, torch):
+    """Box (34 arrays) or triangle (15 arrays + k) ops through the tiled layout: packed on the device, evaluated, unpacked.
+    Returns `words_out` uint32 numpy arrays."""
+    dev = _to_dev(torch, [np.ascontiguousarray(a).view(np.int32) for a in arrays])
+    operands = torch.empty(capi.tiled_words(n, len(arrays)), dtype=torch.int32, device="cuda")
+    results = torch.empty(capi.tiled_words(n, words_out), dtype=torch.int32, device="cuda")
+    out = [torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(words_out)]
+    b = capi.Batch()
+    (b.set_tri_tiled if tri else b.set_box_tiled)(operands, results, n)
+    torch.cuda.synchronize()
+    ctx.tile_pack(dev, operands, n)
+    ctx.launch(b)
+    ctx.tile_unpack(results, out, n)
+    ctx.synchronize()
+    return [o.cpu().numpy().view(u32) for o in out]

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import dp_oracle as O  # noqa: E402  (the checker)
 from raytracer_amd import capi  # noqa: E402
 from oracle import gen  # noqa: E402
-from helpers import hip_angular, hip_box, hip_euclid, hip_tri  # noqa: E402
+from helpers import hip_angular, hip_box, hip_euclid, hip_tiled, hip_tri  # noqa: E402
 
 seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 19
@@ -36,6 +36,11 @@ for s in range(seeds):
     wn, wd, wh = O.tri_soa(tf, tk)
     gn, gd, gh = hip_tri(ctx, tf, tk, device=True, torch=torch)
     ok &= (gn.view(np.uint32) == wn.view(np.uint32)).all() and (gd.view(np.uint32) == wd.view(np.uint32)).all() and (gh == wh).all()
+    # the same ops through the tiled layout
+    tb = hip_tiled(ctx, f, n + s, 5, False, torch)
+    ok &= all((tb[k] == np.asarray(wt[k]).view(np.uint32)).all() for k in range(4)) and (tb[4] == np.asarray(wf).view(np.uint32)).all()
+    tt = hip_tiled(ctx, list(tf) + [tk], n + s, 3, True, torch)
+    ok &= (tt[0] == wn.view(np.uint32)).all() and (tt[1] == wd.view(np.uint32)).all() and (tt[2] == np.asarray(wh).view(np.uint32)).all()
     a, b, ctl, _ = gen.vec_beats(n // 40, 16, seed=3000 + s, edge_frac=edge * 0.3)
     we, _ = O.euclid_beats(a, b, ctl)
     ctx.reset()
