@@ -97,7 +97,7 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=10.0)
     p.add_argument("--knn-log2-points", type=int, default=20)
     p.add_argument("--knn-log2-queries", type=int, default=16)
-    p.add_argument("--stream-mode", type=int, default=0, help="record streams: 0 automatic, 1 partition by opcode first, 2 fused single pass")
+    p.add_argument("--stream-mode", type=int, default=0, help="record streams: 0 automatic, 1 partition by opcode first, 2 evaluate in place then fold the beats, 3 one pass")
     p.add_argument("--trace-wavefront", type=int, default=0, help="1: breadth-first walk with queue compaction; 0: depth-first walk")
     p.add_argument("--trace-sorted", type=int, default=0, help="1: rays sorted by origin / target cell (coherent waves)")
     p.add_argument("--trace-build", default="host", help="host: median-split builder on the CPU; device: rt_dp_bvh4_build_device (Morton order) on the GPU")
@@ -409,7 +409,7 @@ def run_stream(a, world, rank, local, dev):
                           "config": {"workload": "stream: 2^%d EnhancedInputBundle records per GPU resident in HBM, opcode ~ U{0..3}" % a.log2_ops},
                           "roofline": {"bound": "hbm", "achieved": round(n * 420 / per / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(n * 420 / per / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                                       "note": "420 B per record = 336 B record in + 84 B record out; mode %d (1: partition first, moves every live operand twice more; 0/2: fused single pass)" % a.stream_mode}}), flush=True)
+                                       "note": "420 B per record = 336 B record in + 84 B record out; mode %d (1: partition first, moves every live operand twice more; 0/2: evaluate in place, then fold the beats; 3: one pass)" % a.stream_mode}}), flush=True)
     ctx.close()
     dist_util.shutdown()
 

@@ -576,8 +576,10 @@ int rt_dp_set_tuning(rt_dp_ctx *ctx, int ops_per_lane, int nontemporal, int vec_
  * RT_DP_VARIANT.  "wgs_per_cu" (resident 256-thread workgroups per CU of the box / triangle / beat
  * kernels: 0 the measured per-kernel default, 3..16, 99 as many as fit; environment RT_DP_WGS_PER_CU).
  * "stream_mode" selects how rt_dp_eval_bundles_device works: 1 partitions the
- * records by opcode into structure-of-arrays segments first, 2 evaluates them in place in one
- * pass (needs 16-byte aligned record arrays), 0 (default) picks 2 when the alignment allows. */
+ * records by opcode into structure-of-arrays segments first, 2 evaluates them in place and then adds up
+ * the distance beats in a second kernel, 3 does both in one pass with the running sums handed from wave to
+ * wave (2 and 3 need 16-byte aligned record arrays; same results, 2 is the fastest on MI355X),
+ * 0 (default) picks 2 when the alignment allows. */
 int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value);
 /* Reads a knob back as the library resolved it: the keys above give the value in effect ("ops_per_lane",
  * "nontemporal" 0/1, "vec_tile" as requested or 512: it applies to the owning shape of the beat kernels only, whose angular default is 504), and "box_wgs_per_cu" / "tri_wgs_per_cu" give the
@@ -586,7 +588,8 @@ int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value);
  * dynamic LDS a launch asks for; the amount is verified against that query once per process, so a runtime
  * that hands out LDS differently shows up here instead of silently changing the residency.              */
 int rt_dp_get_option(rt_dp_ctx *ctx, const char *key, int *value);
-/* "vec_chain_giveups" (read only): hand-overs between tiles of the beat kernels that were given up on after a
+/* "stream_giveups" (read only): the same count for the hand-overs from wave to wave of stream_mode 3.
+ * "vec_chain_giveups" (read only): hand-overs between tiles of the beat kernels that were given up on after a
  * bounded wait since the context's workspace was last (re)allocated; anything but 0 means the device lost a
  * workgroup and the beat results of that launch are not to be trusted.                                        */
 

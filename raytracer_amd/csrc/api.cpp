@@ -83,7 +83,8 @@ struct rt_dp_ctx {
     uint32_t chain_epoch = 0;
     std::vector<char *> chain_retired;
     Tuning tuning{0, 0, 0, 0, 0, 0};
-    int stream_mode = 0;  // record streams in HBM: 0 automatic, 1 partition by opcode first, 2 fused single pass
+    int stream_mode = 0;  // record streams in HBM: 0 automatic (2 when the arrays allow it), 1 partition by opcode first, 2 evaluate then fold, 3 single pass
+    unsigned long long stream_giveups = 0;  // hand-overs of the single-pass record-stream kernel that were given up on (never, unless a wave is lost)
 };
 
 namespace {
@@ -667,7 +668,54 @@ int rt_dp_eval_bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt
         return RT_DP_OK;
     };
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15u) == 0;
-    if (ctx->stream_mode == 2 && !aligned16) return fail(RT_DP_EALIGN, "the fused record-stream path needs 16-byte aligned record arrays");
+    if ((ctx->stream_mode == 2 || ctx->stream_mode == 3) && !aligned16)
+        return fail(RT_DP_EALIGN, "the fused record-stream paths need 16-byte aligned record arrays");
+    if (ctx->stream_mode == 3) {
+        // ONE pass over the records: every wave evaluates its 64 records and adds up its distance beats in stream order,
+        // the running sums travel from wave to wave (stream_fused.hip: k_stream_chain).  Pieces of 2^26 records bound
+        // the workspace (24 bytes per 64 records of a piece).  Same bits as the two-pass form below, but slower on
+        // MI355X (7.6 against 10.5 G records/s at 2^24 records: the look-back is one more memory round trip in the life
+        // of a wave, and only 7 waves fit a CU next to their 21 KiB of staged records), so it is never chosen by itself.
+        const int lg = env_int("RT_DP_STREAM_CHUNK_LOG2", 26);
+        const uint64_t chunk = 1ull << (lg < 11 ? 11 : (lg > 30 ? 30 : lg));
+        const uint64_t first = n < chunk ? n : chunk;
+        int rc = grow(ctx->d_stream, ctx->stream_bytes, stream_chain_workspace(first));
+        if (rc != RT_DP_OK) return rc;
+        const uint32_t *in_words = reinterpret_cast<const uint32_t *>(d_in);
+        uint32_t *out_words = reinterpret_cast<uint32_t *>(d_out);
+        // all three registers travel in one copy here: bring the Euclidean one over to the angular ones' copy first
+        const int home_e = ctx->cur_e, home_a = ctx->cur_a;
+        if (ctx->extended && home_e != home_a)
+            HIP_TRY(hipMemcpyAsync(ctx->d_state + 4 * home_a, ctx->d_state + 4 * home_e, sizeof(float), hipMemcpyDeviceToDevice, s));
+        int c = home_a;
+        HIP_TRY(hipMemcpyAsync(ctx->d_state + 8, ctx->d_state + 4 * c, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));  // backup
+        HIP_TRY(stream_chain_begin(ctx->d_stream, s));
+        const unsigned long long *sticky = nullptr;
+        for (uint64_t off = 0; off < n; off += chunk) {
+            const uint64_t m = (n - off < chunk) ? (n - off) : chunk;
+            HIP_TRY(stream_chain_eval(in_words + off * 84, m, first, ctx->extended ? 1 : 0, out_words + off * 21, ctx->d_stream, ctx->d_state + 4 * c,
+                                      ctx->d_state + 4 * (c ^ 1), &sticky, s));
+            if (ctx->extended) c ^= 1;
+        }
+        unsigned long long seen[2] = {0, 0};  // {give-ups, opcode > 3}
+        HIP_TRY(hipMemcpyAsync(seen, sticky, sizeof seen, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const bool bad = seen[1] != 0;
+        ctx->stream_giveups += seen[0];
+        if (bad) {  // the registers keep their values from before the call
+            c = home_a;
+            HIP_TRY(hipMemcpy(ctx->d_state + 4 * c, ctx->d_state + 8, 4 * sizeof(float), hipMemcpyDeviceToDevice));
+        }
+        if (ctx->extended) {
+            // all three registers are in copy c now; a register whose address a graph holds goes back to that address
+            if (ctx->pinned_e && c != home_e) HIP_TRY(hipMemcpy(ctx->d_state + 4 * home_e, ctx->d_state + 4 * c, sizeof(float), hipMemcpyDeviceToDevice));
+            if (!ctx->pinned_e) ctx->cur_e = c;
+            if (ctx->pinned_a && c != home_a) HIP_TRY(hipMemcpy(ctx->d_state + 4 * home_a + 1, ctx->d_state + 4 * c + 1, 2 * sizeof(float), hipMemcpyDeviceToDevice));
+            if (!ctx->pinned_a) ctx->cur_a = c;
+        }
+        if (bad) return fail(RT_DP_EOPCODE, "the record stream holds an opcode > 3; the RTL's opcode field is 2 bits wide");
+        return RT_DP_OK;
+    }
     if (ctx->stream_mode == 2 || (ctx->stream_mode == 0 && aligned16)) {
         // one pass over the records: evaluate in place, then add up the distance beats in stream order
         // in pieces of 2^26 records, which bounds the workspace (12 bytes per record of a piece); smaller pieces
@@ -1318,7 +1366,7 @@ int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value) {
         if (!(value == 0 || value == 99 || (value >= 3 && value <= 16))) return fail(RT_DP_EINVAL, "wgs_per_cu must be 0 (default), 3..16, or 99 (no cap)");
         ctx->tuning.wgs_per_cu = value;
     } else if (!strcmp(key, "stream_mode")) {
-        if (value < 0 || value > 2) return fail(RT_DP_EINVAL, "stream_mode must be 0 (automatic), 1 (partition) or 2 (fused)");
+        if (value < 0 || value > 3) return fail(RT_DP_EINVAL, "stream_mode must be 0 (automatic), 1 (partition), 2 (evaluate, then fold) or 3 (single pass)");
         ctx->stream_mode = value;
     } else if (!strcmp(key, "vec_passes")) {
         if (value != 0 && value != 2 && value != 4 && value != 8) return fail(RT_DP_EINVAL, "vec_passes must be 0, 2, 4 or 8");
@@ -1336,6 +1384,7 @@ int rt_dp_get_option(rt_dp_ctx *ctx, const char *key, int *value) {
     if (!strcmp(key, "variant")) *value = ctx->tuning.variant;
     else if (!strcmp(key, "wgs_per_cu")) *value = ctx->tuning.wgs_per_cu;
     else if (!strcmp(key, "stream_mode")) *value = ctx->stream_mode;
+    else if (!strcmp(key, "stream_giveups")) *value = (int)(ctx->stream_giveups > 0x7FFFFFFFull ? 0x7FFFFFFFull : ctx->stream_giveups);
     else if (!strcmp(key, "vec_passes")) *value = ctx->tuning.vec_passes ? ctx->tuning.vec_passes : 0;
     else if (!strcmp(key, "ops_per_lane")) *value = ctx->tuning.ops_per_lane ? ctx->tuning.ops_per_lane : 1;
     else if (!strcmp(key, "nontemporal")) *value = ctx->tuning.nontemporal == 2 ? 0 : 1;

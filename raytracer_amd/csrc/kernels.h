@@ -106,6 +106,11 @@ hipError_t stream_fused_begin(char *workspace, uint64_t capacity, hipStream_t s)
 hipError_t stream_fused_eval(const uint32_t *in, uint64_t n, uint64_t capacity, int extended, uint32_t *out, char *workspace,
                              StreamSideView *view, hipStream_t s);
 hipError_t stream_fused_fold(const StreamSideView &v, uint64_t n, const float *state_in, float *state_out, uint32_t *out, hipStream_t s);
+// the same in one pass (running sums handed from wave to wave); state_in / state_out: {euclid, dot, norm}
+size_t stream_chain_workspace(uint64_t capacity);
+hipError_t stream_chain_begin(char *workspace, hipStream_t s);
+hipError_t stream_chain_eval(const uint32_t *in, uint64_t n, uint64_t capacity, int extended, uint32_t *out, char *workspace, const float *state_in,
+                             float *state_out, const unsigned long long **sticky_out, hipStream_t s);
 
 // hit-mask compaction behind a Quadbox batch (compact.hip); blockcnt [ceil(n/256)] u32, offsets64 likewise u64, total one u64.
 // tile_words 0: flags / tmin are plain arrays; kBoxOutWords: they point at their word's run in tile 0 of a tiled result buffer

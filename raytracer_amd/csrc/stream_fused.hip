@@ -58,38 +58,21 @@ __device__ __forceinline__ float tree8(const float (&s)[8]) {  // (i, i+4), (i, 
     return (t[0] + t[2]) + (t[1] + t[3]);
 }
 
-__global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__ in, uint64_t n, int extended, uint32_t *__restrict__ out,
-                                                    StreamSide side) {
-    __shared__ __align__(16) uint32_t s_rec[kWaveRecs * kRecIn];  // 21 KiB; re-used for the output records
-    const int lane = threadIdx.x;
-    const uint64_t r0 = (uint64_t)blockIdx.x * kWaveRecs;
-    const uint32_t live = (n - r0 < (uint64_t)kWaveRecs) ? (uint32_t)(n - r0) : (uint32_t)kWaveRecs;
-
-    // coalesced copy of the wave's records into LDS (record r, word w -> s_rec[84 r + w])
-    {
-        const u4v *src = reinterpret_cast<const u4v *>(in + r0 * kRecIn);
-        const uint32_t chunks = live * (kRecIn / 4);
-        u4v v[kRecIn / 4];
-#pragma unroll
-        for (int j = 0; j < kRecIn / 4; ++j) {
-            const uint32_t g = (uint32_t)j * 64u + lane;
-            v[j] = (g < chunks) ? __builtin_nontemporal_load(src + g) : u4v{0u, 0u, 0u, 0u};
-        }
-#pragma unroll
-        for (int j = 0; j < kRecIn / 4; ++j) reinterpret_cast<u4v *>(s_rec)[j * 64 + lane] = v[j];
-    }
-    __syncthreads();
-
+// One lane evaluates the record it owns (s_rec + 84 * lane): Quadbox and triangle ops completely, for a distance beat the
+// tree sum(s) of the beat, which do not depend on the accumulator.  w: the 21 output words (accumulator fields still 0).
+// Returns false when the opcode is not one of the four.
+__device__ __forceinline__ bool stream_eval_record(const uint32_t *s_rec, int lane, bool have, int extended, uint32_t (&w)[kRecOut], uint32_t &op,
+                                                   uint32_t &reset, float &sum0, float &sum1) {
+    bool known = true;
     // 16-byte LDS reads of the own record: 21 is odd, so the lanes of a read spread over all banks
     const u4v *rc = reinterpret_cast<const u4v *>(s_rec + lane * kRecIn);
-    const bool have = (uint32_t)lane < live;
     const u4v c0 = rc[0];
-    const uint32_t op = have ? c0.x : 0xFFFFFFFFu;
-    const uint32_t reset = have ? (rc[20].w & 1u) : 0u;
-    uint32_t w[kRecOut];
+    op = have ? c0.x : 0xFFFFFFFFu;
+    reset = have ? (rc[20].w & 1u) : 0u;
 #pragma unroll
     for (int k = 0; k < kRecOut; ++k) w[k] = 0u;
-    float sum0 = 0.0f, sum1 = 0.0f;
+    sum0 = 0.0f;
+    sum1 = 0.0f;
     if (have) {
         w[0] = op;
         if (extended) { w[17] = reset; w[20] = reset; }
@@ -164,8 +147,38 @@ __global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__
         sum0 = tree8(s);
         sum1 = tree8(m);
     } else if (have) {
-        atomicOr(&side.flags[8], 1u);  // cannot occur in the RTL's 2-bit field
+        known = false;  // cannot occur in the RTL's 2-bit field
     }
+    return known;
+}
+
+
+__global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__ in, uint64_t n, int extended, uint32_t *__restrict__ out,
+                                                    StreamSide side) {
+    __shared__ __align__(16) uint32_t s_rec[kWaveRecs * kRecIn];  // 21 KiB; re-used for the output records
+    const int lane = threadIdx.x;
+    const uint64_t r0 = (uint64_t)blockIdx.x * kWaveRecs;
+    const uint32_t live = (n - r0 < (uint64_t)kWaveRecs) ? (uint32_t)(n - r0) : (uint32_t)kWaveRecs;
+
+    // coalesced copy of the wave's records into LDS (record r, word w -> s_rec[84 r + w])
+    {
+        const u4v *src = reinterpret_cast<const u4v *>(in + r0 * kRecIn);
+        const uint32_t chunks = live * (kRecIn / 4);
+        u4v v[kRecIn / 4];
+#pragma unroll
+        for (int j = 0; j < kRecIn / 4; ++j) {
+            const uint32_t g = (uint32_t)j * 64u + lane;
+            v[j] = (g < chunks) ? __builtin_nontemporal_load(src + g) : u4v{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int j = 0; j < kRecIn / 4; ++j) reinterpret_cast<u4v *>(s_rec)[j * 64 + lane] = v[j];
+    }
+    __syncthreads();
+
+    const bool have = (uint32_t)lane < live;
+    uint32_t w[kRecOut], op, reset;
+    float sum0, sum1;
+    if (!stream_eval_record(s_rec, lane, have, extended, w, op, reset, sum0, sum1)) atomicOr(&side.flags[8], 1u);
 
     if (have) {
         side.tag[r0 + lane] = (op & 3u) | (reset << 2);
@@ -343,6 +356,244 @@ __global__ __launch_bounds__(kFoldThreads) void k_stream_fold(StreamSideView v, 
     } else {
         if (v.flags[2]) stream_fold<false>(v.tag, v.sum0, v.sum1, v.rbits[1], n, tile, state_in + 1, state_out + 1, out);
     }
+}
+
+// ---- the single-pass form ------------------------------------------------------------------------------------
+// k_stream_chain does everything k_stream_eval and k_stream_fold do in ONE pass over the records: the output records are
+// written once, complete, and no per-record side arrays exist.  A wave still owns 64 consecutive records.  Per distance
+// opcode X it adds up its own X beats in stream order inside the wave (a loop over the set bits of a ballot; the running
+// sum is wave-uniform), and the running sum that enters the wave comes from the waves before it through one 64-bit word
+// per wave and sum, {state, float bits}, in a workspace that is zeroed before the launch:
+//   state 0  not published yet
+//   state 1  "transparent": the wave holds no beat of X, the sum passes through it unchanged
+//   state 2  the running sum of X behind the wave's last record
+// A wave that holds a reset of X knows its outgoing sum without knowing the incoming one (only the beats behind its last
+// reset count) and publishes it before it looks back; a wave without a reset publishes after it has received the incoming
+// sum.  Looking back, the 64 lanes examine the 64 nearest predecessors at once and skip transparent ones; in front of
+// wave 0 stand the registers that enter the stream.  The arithmetic is the same strictly sequential float sum per vector
+// pair in the same order as in k_stream_fold, so the bits are the same.
+//
+// Progress: a wave waits only for waves with a lower index, which were dispatched before it and wait, if at all, for still
+// lower ones; wave 0 never waits.  The wait is bounded all the same (a lost wave must not hang the device): after
+// kStreamSpins polls a give-up is counted in the header and the wave goes on with +0.
+constexpr int kStreamSpins = 1 << 20;
+
+struct StreamChain {
+    unsigned long long *sticky;   // [0] give-ups, [1] an opcode > 3 was seen; cleared once per call
+    uint32_t *last;               // [0], [1]: 1 + index of the last wave that published a sum of opcode 2 / 3 (0: none); per piece
+    unsigned long long *word[3];  // [waves] each: Euclidean sum, angular dot, angular norm
+};
+
+__device__ __forceinline__ unsigned long long stream_word(uint32_t state, float v) {
+    return ((unsigned long long)state << 32) | (unsigned long long)__float_as_uint(v);
+}
+
+// The X beats selected by `todo` (a subset of the wave's lanes, ascending = stream order) are added onto acc one by one;
+// the owning lane keeps its beat's result in res; a beat with its reset bit restarts the sum from +0 behind it.
+template <bool TWO>
+__device__ __forceinline__ void stream_wave_walk(unsigned long long todo, unsigned long long resets, float s0, float s1, int lane, float &acc0,
+                                                 float &acc1, float &res0, float &res1) {
+    while (todo) {
+        const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+        todo &= todo - 1;
+        const bool rs = (resets >> L) & 1ull;
+        const float o0 = acc0 + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s0), L));
+        if (lane == L) res0 = o0;
+        acc0 = rs ? 0.0f : o0;
+        if (TWO) {
+            const float o1 = acc1 + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s1), L));
+            if (lane == L) res1 = o1;
+            acc1 = rs ? 0.0f : o1;
+        }
+    }
+}
+
+// The running sum(s) of opcode X in front of wave `b`: the nearest predecessor that is not transparent, polled until it has
+// published.  Executed by the whole wave (uniform control flow).
+template <bool TWO>
+__device__ __forceinline__ void stream_look_back(const unsigned long long *w0, const unsigned long long *w1, long long b, float in0, float in1,
+                                                 int lane, unsigned long long *giveups, float &c0, float &c1) {
+    long long top = b - 1;  // the nearest predecessor not yet known to be transparent
+    for (int spin = 0; spin < kStreamSpins; ++spin) {
+        const long long idx = top - lane;
+        uint32_t st = 2u;
+        float v0 = in0, v1 = in1;  // in front of wave 0: the registers entering the stream
+        if (idx >= 0) {
+            const unsigned long long a = __hip_atomic_load(w0 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st = (uint32_t)(a >> 32);
+            v0 = __uint_as_float((uint32_t)a);
+            if (TWO) {
+                const unsigned long long c = __hip_atomic_load(w1 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(c >> 32) != st) st = 0u;  // the second word is not there yet
+                v1 = __uint_as_float((uint32_t)c);
+            }
+        }
+        const unsigned long long opaque = __ballot(st != 1u);
+        if (!opaque) { top -= 64; continue; }  // 64 transparent waves: look further back (lanes in front of wave 0 count as published, so this ends)
+        const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)opaque) - 1);
+        const uint32_t stL = (uint32_t)__builtin_amdgcn_readlane((int)st, L);
+        if (stL == 2u) {
+            c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v0), L));
+            c1 = TWO ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v1), L)) : 0.0f;
+            return;
+        }
+        top -= L;  // everything nearer than L is transparent; L itself has not published yet
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (lane == 0) atomicAdd(giveups, 1ull);
+    c0 = 0.0f;
+    c1 = 0.0f;
+}
+
+// One distance opcode of one wave: publish, look back, accumulate.  e: lanes holding a beat of X, r: those with the reset bit.
+template <bool TWO>
+__device__ __forceinline__ void stream_wave_fold(unsigned long long e, unsigned long long r, float s0, float s1, int lane, long long b,
+                                                 unsigned long long *w0, unsigned long long *w1, const float *state_in, unsigned long long *giveups,
+                                                 float &res0, float &res1) {
+    if (!e) {  // no beat of X here: the sum passes through
+        if (lane == 0) {
+            __hip_atomic_store(w0 + b, stream_word(1u, 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (TWO) __hip_atomic_store(w1 + b, stream_word(1u, 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    unsigned long long head = e;  // the beats that continue whatever runs into this wave: up to and including the first reset
+    if (r) {
+        const int lo = __ffsll((long long)r) - 1;
+        head = e & ((lo == 63) ? ~0ull : ((2ull << lo) - 1ull));
+        // everything behind the first reset starts from +0, and what is left behind the last reset is the outgoing sum
+        float a0 = 0.0f, a1 = 0.0f;
+        stream_wave_walk<TWO>(e & ~head, r, s0, s1, lane, a0, a1, res0, res1);
+        if (lane == 0) {
+            __hip_atomic_store(w0 + b, stream_word(2u, a0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (TWO) __hip_atomic_store(w1 + b, stream_word(2u, a1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    float c0, c1;
+    stream_look_back<TWO>(w0, w1, b, state_in[0], TWO ? state_in[1] : 0.0f, lane, giveups, c0, c1);
+    stream_wave_walk<TWO>(head, r, s0, s1, lane, c0, c1, res0, res1);
+    if (!r && lane == 0) {  // no reset in this wave: the outgoing sum is the incoming one plus all of its beats
+        __hip_atomic_store(w0 + b, stream_word(2u, c0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (TWO) __hip_atomic_store(w1 + b, stream_word(2u, c1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_stream_chain(const uint32_t *__restrict__ in, uint64_t n, int extended, uint32_t *__restrict__ out,
+                                                     StreamChain ch, const float *__restrict__ state_in) {
+    __shared__ __align__(16) uint32_t s_rec[kWaveRecs * kRecIn];  // 21 KiB; re-used for the output records
+    const int lane = threadIdx.x;
+    const uint64_t r0 = (uint64_t)blockIdx.x * kWaveRecs;
+    const uint32_t live = (n - r0 < (uint64_t)kWaveRecs) ? (uint32_t)(n - r0) : (uint32_t)kWaveRecs;
+    {
+        const u4v *src = reinterpret_cast<const u4v *>(in + r0 * kRecIn);
+        const uint32_t chunks = live * (kRecIn / 4);
+        u4v v[kRecIn / 4];
+#pragma unroll
+        for (int j = 0; j < kRecIn / 4; ++j) {
+            const uint32_t g = (uint32_t)j * 64u + lane;
+            v[j] = (g < chunks) ? __builtin_nontemporal_load(src + g) : u4v{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int j = 0; j < kRecIn / 4; ++j) reinterpret_cast<u4v *>(s_rec)[j * 64 + lane] = v[j];
+    }
+    __syncthreads();
+    const bool have = (uint32_t)lane < live;
+    uint32_t w[kRecOut], op, reset;
+    float sum0, sum1;
+    const bool known = stream_eval_record(s_rec, lane, have, extended, w, op, reset, sum0, sum1);
+    if (__ballot(!known) && lane == 0) atomicOr(ch.sticky + 1, 1ull);
+
+    if (extended) {
+        const long long b = blockIdx.x;
+        float e0 = 0.0f, unused = 0.0f, d0 = 0.0f, d1 = 0.0f;
+        stream_wave_fold<false>(__ballot(op == 2u), __ballot(op == 2u && reset != 0u), sum0, 0.0f, lane, b, ch.word[0], nullptr, state_in, ch.sticky,
+                                e0, unused);
+        stream_wave_fold<true>(__ballot(op == 3u), __ballot(op == 3u && reset != 0u), sum0, sum1, lane, b, ch.word[1], ch.word[2], state_in + 1, ch.sticky,
+                               d0, d1);
+        if (op == 2u) w[16] = __float_as_uint(canon_nan(e0));
+        if (op == 3u) { w[18] = __float_as_uint(canon_nan(d0)); w[19] = __float_as_uint(canon_nan(d1)); }
+    }
+
+    __syncthreads();  // every lane has read its record: the buffer now takes the output records
+#pragma unroll
+    for (int k = 0; k < kRecOut; ++k) s_rec[lane * kRecOut + k] = w[k];  // stride 21 words is odd: conflict-free
+    __syncthreads();
+    uint32_t *dst = out + r0 * kRecOut;
+    if (live == (uint32_t)kWaveRecs) {  // 1344 words = 336 chunks of 16 bytes
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int g = j * 64 + lane;
+            if (g < kWaveRecs * kRecOut / 4) __builtin_nontemporal_store(reinterpret_cast<const u4v *>(s_rec)[g], reinterpret_cast<u4v *>(dst) + g);
+        }
+    } else {
+        for (uint32_t g = lane; g < live * kRecOut; g += 64) dst[g] = s_rec[g];
+    }
+}
+
+// The registers behind the last record: the sum published by the last wave that is not transparent (the words are final
+// once k_stream_chain has finished), or the entering registers when no wave held a beat of the opcode.
+__global__ __launch_bounds__(1024) void k_stream_chain_last(StreamChain ch, uint32_t waves) {
+    __shared__ uint32_t s_last[2];
+    if (threadIdx.x < 2) s_last[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+    if (i < waves) {
+        if ((uint32_t)(ch.word[0][i] >> 32) == 2u) atomicMax(&s_last[0], i + 1u);
+        if ((uint32_t)(ch.word[1][i] >> 32) == 2u) atomicMax(&s_last[1], i + 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_last[threadIdx.x]) atomicMax(ch.last + threadIdx.x, s_last[threadIdx.x]);
+}
+
+__global__ void k_stream_chain_state(StreamChain ch, const float *__restrict__ state_in, float *__restrict__ state_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t le = ch.last[0], la = ch.last[1];
+    state_out[0] = le ? canon_nan(__uint_as_float((uint32_t)ch.word[0][le - 1u])) : state_in[0];
+    state_out[1] = la ? canon_nan(__uint_as_float((uint32_t)ch.word[1][la - 1u])) : state_in[1];
+    state_out[2] = la ? canon_nan(__uint_as_float((uint32_t)ch.word[2][la - 1u])) : state_in[2];
+}
+
+static StreamChain stream_chain_layout(char *workspace, uint64_t capacity, size_t *piece_bytes) {
+    const uint64_t waves = (capacity + 63) / 64;
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    StreamChain ch;
+    size_t o = 0;
+    ch.sticky = reinterpret_cast<unsigned long long *>(workspace + o); o += 256;
+    const size_t piece0 = o;
+    ch.last = reinterpret_cast<uint32_t *>(workspace + o); o += 256;
+    for (int k = 0; k < 3; ++k) { ch.word[k] = reinterpret_cast<unsigned long long *>(workspace + o); o += up(waves * 8); }
+    if (piece_bytes) *piece_bytes = o - piece0;
+    return ch;
+}
+
+size_t stream_chain_workspace(uint64_t capacity) {
+    size_t piece = 0;
+    (void)stream_chain_layout(nullptr, capacity, &piece);
+    return 256 + piece;
+}
+
+// Clears the give-up counter and the sticky "opcode > 3" word; once per call, before the first piece.
+hipError_t stream_chain_begin(char *workspace, hipStream_t s) { return hipMemsetAsync(workspace, 0, 256, s); }
+
+// One piece of n <= capacity records in one pass; state_in / state_out: {euclid, dot, norm} in front of / behind the piece.
+// *sticky_out: device address of {give-ups, opcode > 3 seen} (two 64-bit words) for the caller to read back.
+hipError_t stream_chain_eval(const uint32_t *in, uint64_t n, uint64_t capacity, int extended, uint32_t *out, char *workspace, const float *state_in,
+                             float *state_out, const unsigned long long **sticky_out, hipStream_t s) {
+    size_t piece = 0;
+    const StreamChain ch = stream_chain_layout(workspace, capacity, &piece);
+    const uint64_t waves = (n + 63) / 64;
+    if (n > capacity || waves > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (sticky_out) *sticky_out = ch.sticky;
+    if (extended) {  // every word starts as "not published"
+        hipError_t e = hipMemsetAsync(ch.last, 0, piece, s);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_stream_chain, dim3((unsigned)waves), dim3(64), 0, s, in, n, extended, out, ch, state_in);
+    if (extended) {
+        hipLaunchKernelGGL(k_stream_chain_last, dim3((unsigned)((waves + 1023) / 1024)), dim3(1024), 0, s, ch, (uint32_t)waves);
+        hipLaunchKernelGGL(k_stream_chain_state, dim3(1), dim3(64), 0, s, ch, state_in, state_out);
+    }
+    return hipGetLastError();
 }
 
 // Workspace for pieces of at most `capacity` records: tag, sum0, sum1, the two bit arrays, 256 bytes of flags.

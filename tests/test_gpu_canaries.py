@@ -57,7 +57,7 @@ def test_op_batches_stay_inside_their_outputs(torch_cuda, n):
 
 
 @pytest.mark.parametrize("n", SIZES)
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_record_streams_stay_inside_their_output(torch_cuda, n, mode):
     torch = torch_cuda
     g = Guarded(torch)

@@ -356,9 +356,9 @@ def _mixed_stream(seed, nb, nt, pe, pa, edge=0.3):
 @pytest.mark.parametrize("sizes", [(1, 0, 0, 0), (0, 0, 1, 0), (3, 2, 1, 1), (0, 0, 0, 30), (0, 0, 50, 0), (300, 300, 40, 40),
                                    (20000, 20000, 3000, 3000), (60000, 10, 2, 900)])
 @pytest.mark.parametrize("extended", [True, False])
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_device_record_stream_matches_rtl_oracle(oracle, torch_cuda, sizes, extended, mode):
-    """rt_dp_eval_bundles_device (1: partition by opcode first, 2: fused single pass) against oracle A."""
+    """rt_dp_eval_bundles_device (1: partition by opcode first, 2: evaluate in place then fold, 3: single pass) against oracle A."""
     torch = torch_cuda
     stream = _mixed_stream(60 + sizes[0], *sizes)
     c = capi.Context(support_euclidean=16 if extended else 0)
@@ -381,7 +381,7 @@ def test_device_record_stream_matches_rtl_oracle(oracle, torch_cuda, sizes, exte
     c.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_device_record_stream_carries_accumulators(oracle, torch_cuda, mode):
     """A stream cut at arbitrary records (inside vector pairs) and fed in pieces equals the stream fed whole; a stream
     of distance beats without any reset is one long pair."""
@@ -410,3 +410,79 @@ def test_device_record_stream_carries_accumulators(oracle, torch_cuda, mode):
     assert_bits_equal(d_out.cpu().numpy().view(u32), want.view(u32).reshape(-1, 21), "endless pair")
     assert tuple(int(x) for x in c.get_accum().view(u32)) == state
     c.close()
+
+
+def _single_pass_case(oracle, torch, stream, what, chunk_log2=None, monkeypatch=None):
+    """One stream through the single-pass record-stream kernel against oracle B, registers included, twice in a row on one
+    context (the second call continues the first one's registers)."""
+    if chunk_log2 is not None:
+        monkeypatch.setenv("RT_DP_STREAM_CHUNK_LOG2", str(chunk_log2))
+    c = capi.Context()
+    c.set_option("stream_mode", 3)
+    two = np.ascontiguousarray(np.concatenate([stream, stream]))
+    want, state = oracle.eval_bundles("B", two.view(oracle.IN_BUNDLE).reshape(-1), extended=True)
+    want = want.view(u32).reshape(-1, 21)
+    d_in = torch.from_numpy(stream.view(np.int32)).cuda()
+    n = stream.shape[0]
+    for half in range(2):
+        d_out = torch.full((n, 21), -1, dtype=torch.int32, device="cuda")
+        c.eval_bundles_device(d_in, d_out)
+        assert_bits_equal(d_out.cpu().numpy().view(u32), want[half * n:(half + 1) * n], "%s, call %d" % (what, half))
+    assert tuple(int(x) for x in c.get_accum().view(u32)) == state, what
+    assert c.get_option("stream_giveups") == 0
+    c.close()
+
+
+def test_single_pass_record_stream_long_stretches_without_an_opcode(oracle, torch_cuda):
+    """The running sum of a vector pair has to cross thousands of records that hold no beat of its opcode: the look-back skips
+    the waves in between 64 at a time."""
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    a, b, ctl, _ = gen.vec_beats(6, 16, seed=51, lengths=[40, 100, 16, 128, 7, 90])
+    q, cnd, ctl8, _ = gen.vec_beats(5, 8, seed=52, lengths=[30, 64, 8, 100, 50])
+    we, wa = gen.aos_from_vec(a, b, ctl, 2), gen.aos_from_vec(q, cnd, ctl8, 3)
+    box = gen.aos_from_box(gen.box_ops(40000, seed=53, edge_frac=0.1))
+    tri = gen.aos_from_tri(*gen.tri_ops(9000, seed=54, edge_frac=0.1))
+    # beats of both distance opcodes sprinkled singly into long runs of box / triangle records: pairs stay open across the runs
+    parts, eb, ab = [], list(we), list(wa)
+    pos = 0
+    while eb or ab:
+        run = int(rng.integers(1, 9000))
+        parts.append(box[pos % 30000:pos % 30000 + run])
+        pos += run
+        if eb and (not ab or rng.random() < 0.5):
+            parts.append(eb.pop(0)[None, :])
+        elif ab:
+            parts.append(ab.pop(0)[None, :])
+        parts.append(tri[:int(rng.integers(0, 200))])
+    stream = np.ascontiguousarray(np.concatenate(parts)).astype(u32)
+    stream[stream[:, 0] < 2, 83] = 1
+    assert stream.shape[0] > 100000
+    _single_pass_case(oracle, torch, stream, "sparse distance beats")
+
+
+@pytest.mark.parametrize("kind", ["box_only", "euclid_only", "angular_only", "no_reset", "reset_everywhere", "tail_of_7"])
+def test_single_pass_record_stream_corner_streams(oracle, torch_cuda, kind):
+    torch = torch_cuda
+    base = _mixed_stream(90, 3000, 3000, 500, 500)
+    if kind == "box_only":
+        stream = base[base[:, 0] == 1]
+    elif kind == "euclid_only":
+        stream = base[base[:, 0] == 2]
+    elif kind == "angular_only":
+        stream = base[base[:, 0] == 3]
+    elif kind == "no_reset":
+        stream = base.copy()
+        stream[stream[:, 0] >= 2, 83] = 0
+    elif kind == "reset_everywhere":
+        stream = base.copy()
+        stream[:, 83] = 1
+    else:
+        stream = base[:7]
+    _single_pass_case(oracle, torch, np.ascontiguousarray(stream), kind)
+
+
+def test_single_pass_record_stream_in_pieces(oracle, torch_cuda, monkeypatch):
+    """Pieces of 2^11 records inside one call: the registers travel from piece to piece on the device."""
+    stream = _mixed_stream(91, 4000, 4000, 600, 600)
+    _single_pass_case(oracle, torch_cuda, stream, "2^11-record pieces", chunk_log2=11, monkeypatch=monkeypatch)
