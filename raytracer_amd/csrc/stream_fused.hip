@@ -36,7 +36,7 @@ constexpr int kRecOut = 21;   // words per rt_dp_output_bundle
 constexpr int kWaveRecs = 64;
 
 struct StreamSide {
-    uint32_t *tag;        // [n]   opcode | reset << 2
+    uint32_t *tag;        // [n]   opcode | reset << 2 | outputs final << 3
     float *sum0, *sum1;   // [n]   tree sums of a distance beat (Euclidean: sum0; angular: dot, norm)
     uint32_t *rbits[2];   // [ceil(n / 2048)] bit b of word w: records [(32 w + b) * 64, +64) hold a reset of opcode 2 / 3
     uint32_t *flags;      // [1] opcode 2 present, [2] opcode 3 present (per launch); [8] an opcode > 3 was seen (sticky)
@@ -153,6 +153,26 @@ __device__ __forceinline__ bool stream_eval_record(const uint32_t *s_rec, int la
 }
 
 
+// The X beats selected by `todo` (a subset of the wave's lanes, ascending = stream order) are added onto acc one by one;
+// the owning lane keeps its beat's result in res; a beat with its reset bit restarts the sum from +0 behind it.
+template <bool TWO>
+__device__ __forceinline__ void stream_wave_walk(unsigned long long todo, unsigned long long resets, float s0, float s1, int lane, float &acc0,
+                                                 float &acc1, float &res0, float &res1) {
+    while (todo) {
+        const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+        todo &= todo - 1;
+        const bool rs = (resets >> L) & 1ull;
+        const float o0 = acc0 + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s0), L));
+        if (lane == L) res0 = o0;
+        acc0 = rs ? 0.0f : o0;
+        if (TWO) {
+            const float o1 = acc1 + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s1), L));
+            if (lane == L) res1 = o1;
+            acc1 = rs ? 0.0f : o1;
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__ in, uint64_t n, int extended, uint32_t *__restrict__ out,
                                                     StreamSide side) {
     __shared__ __align__(16) uint32_t s_rec[kWaveRecs * kRecIn];  // 21 KiB; re-used for the output records
@@ -180,8 +200,32 @@ __global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__
     float sum0, sum1;
     if (!stream_eval_record(s_rec, lane, have, extended, w, op, reset, sum0, sum1)) atomicOr(&side.flags[8], 1u);
 
+    // Beats behind the first reset of their opcode in this wave start from +0 whatever came before: their accumulator
+    // outputs are final here and travel with the record's coalesced store.  Only the beats in front of the first reset
+    // (they continue a pair from an earlier wave) are left to k_stream_fold, which then has that many fewer 4-byte
+    // patches to write into finished records.
+    uint32_t fin = 0u;
+    if (extended) {
+        const unsigned long long e2 = __ballot(op == 2u), r2 = __ballot(op == 2u && reset != 0u);
+        const unsigned long long e3 = __ballot(op == 3u), r3 = __ballot(op == 3u && reset != 0u);
+        if (r2) {
+            const int lo = __ffsll((long long)r2) - 1;
+            const unsigned long long rest = e2 & ~((lo == 63) ? ~0ull : ((2ull << lo) - 1ull));
+            float a0 = 0.0f, a1 = 0.0f, res = 0.0f, none = 0.0f;
+            stream_wave_walk<false>(rest, r2, sum0, 0.0f, lane, a0, a1, res, none);
+            if ((rest >> lane) & 1ull) { w[16] = __float_as_uint(canon_nan(res)); fin = 1u; }
+        }
+        if (r3) {
+            const int lo = __ffsll((long long)r3) - 1;
+            const unsigned long long rest = e3 & ~((lo == 63) ? ~0ull : ((2ull << lo) - 1ull));
+            float a0 = 0.0f, a1 = 0.0f, res0 = 0.0f, res1 = 0.0f;
+            stream_wave_walk<true>(rest, r3, sum0, sum1, lane, a0, a1, res0, res1);
+            if ((rest >> lane) & 1ull) { w[18] = __float_as_uint(canon_nan(res0)); w[19] = __float_as_uint(canon_nan(res1)); fin = 1u; }
+        }
+    }
+
     if (have) {
-        side.tag[r0 + lane] = (op & 3u) | (reset << 2);
+        side.tag[r0 + lane] = (op & 3u) | (reset << 2) | (fin << 3);
         side.sum0[r0 + lane] = sum0;
         side.sum1[r0 + lane] = sum1;
     }
@@ -233,7 +277,7 @@ __device__ __forceinline__ uint64_t stream_boundary(const uint32_t *tag, const u
             i = ((w0 + wl) * 32 + (__ffs((int)first) - 1)) << 6;  // the first 64-record block holding a reset of X
         }
         const uint64_t b0 = i & ~63ull, idx = b0 + lane;
-        const bool p = idx >= i && idx < n && tag[idx] == want;
+        const bool p = idx >= i && idx < n && (tag[idx] & 7u) == want;
         const unsigned long long m = __ballot(p);
         if (m) return b0 + (uint64_t)(__ffsll((long long)m) - 1) + 1;
         i = b0 + 64;
@@ -294,7 +338,7 @@ __device__ __forceinline__ void stream_fold(const uint32_t *__restrict__ tag, co
                 const uint32_t k = before + (uint32_t)__popcll(mk[u] & ((1ull << lane) - 1ull));
                 c_sum0[k] = sum0[base + p];
                 if (!EUC) c_sum1[k] = sum1[base + p];
-                c_rs[k] = (uint8_t)((tg[u] >> 2) & 1u);
+                c_rs[k] = (uint8_t)((tg[u] >> 2) & 3u);  // bit 0: reset, bit 1: the output is already in the record
                 c_pos[k] = (uint16_t)p;
             }
         }
@@ -304,7 +348,7 @@ __device__ __forceinline__ void stream_fold(const uint32_t *__restrict__ tag, co
 
         // one lane per vector pair accumulates its beats in order
         for (int t0 = tid; t0 < m; t0 += kFoldThreads) {
-            const bool starts = (t0 == 0) || (c_rs[t0 - 1] != 0);
+            const bool starts = (t0 == 0) || ((c_rs[t0 - 1] & 1u) != 0);
             if (starts) {
                 float acc0 = (t0 == 0) ? s_carry[par][0] : 0.0f;
                 float acc1 = (t0 == 0) ? s_carry[par][1] : 0.0f;
@@ -313,7 +357,7 @@ __device__ __forceinline__ void stream_fold(const uint32_t *__restrict__ tag, co
                 do {
                     const float o0 = acc0 + c_sum0[i];
                     c_out0[i] = canon_nan(o0);
-                    rs = c_rs[i] != 0;
+                    rs = (c_rs[i] & 1u) != 0;
                     acc0 = rs ? 0.0f : o0;
                     if (!EUC) {
                         const float o1 = acc1 + c_sum1[i];
@@ -330,6 +374,7 @@ __device__ __forceinline__ void stream_fold(const uint32_t *__restrict__ tag, co
         }
         __syncthreads();
         for (int t0 = tid; t0 < m; t0 += kFoldThreads) {  // partial-line writes: without nt each one pulls its line into L2 first
+            if (c_rs[t0] & 2u) continue;  // k_stream_eval wrote this beat's outputs with the record
             uint32_t *rec = out + (base + c_pos[t0]) * kRecOut;
             if (EUC) {
                 __builtin_nontemporal_store(__float_as_uint(c_out0[t0]), rec + 16);
@@ -386,26 +431,6 @@ struct StreamChain {
 
 __device__ __forceinline__ unsigned long long stream_word(uint32_t state, float v) {
     return ((unsigned long long)state << 32) | (unsigned long long)__float_as_uint(v);
-}
-
-// The X beats selected by `todo` (a subset of the wave's lanes, ascending = stream order) are added onto acc one by one;
-// the owning lane keeps its beat's result in res; a beat with its reset bit restarts the sum from +0 behind it.
-template <bool TWO>
-__device__ __forceinline__ void stream_wave_walk(unsigned long long todo, unsigned long long resets, float s0, float s1, int lane, float &acc0,
-                                                 float &acc1, float &res0, float &res1) {
-    while (todo) {
-        const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-        todo &= todo - 1;
-        const bool rs = (resets >> L) & 1ull;
-        const float o0 = acc0 + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s0), L));
-        if (lane == L) res0 = o0;
-        acc0 = rs ? 0.0f : o0;
-        if (TWO) {
-            const float o1 = acc1 + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s1), L));
-            if (lane == L) res1 = o1;
-            acc1 = rs ? 0.0f : o1;
-        }
-    }
 }
 
 // The running sum(s) of opcode X in front of wave `b`: the nearest predecessor that is not transparent, polled until it has
