@@ -674,7 +674,7 @@ int rt_dp_eval_bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt
         // ONE pass over the records: every wave evaluates its 64 records and adds up its distance beats in stream order,
         // the running sums travel from wave to wave (stream_fused.hip: k_stream_chain).  Pieces of 2^26 records bound
         // the workspace (24 bytes per 64 records of a piece).  Same bits as the two-pass form below, but slower on
-        // MI355X (7.6 against 10.5 G records/s at 2^24 records: the look-back is one more memory round trip in the life
+        // MI355X (7.6 against 11.4 G records/s at 2^24 records: the look-back is one more memory round trip in the life
         // of a wave, and only 7 waves fit a CU next to their 21 KiB of staged records), so it is never chosen by itself.
         const int lg = env_int("RT_DP_STREAM_CHUNK_LOG2", 26);
         const uint64_t chunk = 1ull << (lg < 11 ? 11 : (lg > 30 ? 30 : lg));
