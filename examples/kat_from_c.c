@@ -1,5 +1,5 @@
 /* The C ABI from plain C: the four known-answer cases of the datapath (one per opcode) through
- * rt_dp_eval with host arrays.  Every intermediate value is exact in binary32, so the expected bit
+ * rt_dp_eval with host arrays, then the box and triangle cases again as tiled segments.  Every intermediate value is exact in binary32, so the expected bit
  * patterns follow from the RTL's dataflow by hand (reference
  * src/main/scala/raytracer_datapath/UnifiedDatapath.scala: Quadbox :167-220, :534-631, :1117-1132;
  * triangle :118-166 ... :1087-1116; Euclidean :221-245, :632-649, :1133-1154; angular :246-268,
@@ -85,6 +85,66 @@ int main(void) {
     bad += expect("euclidean beat 2", bits(eacc[2]), 0x44AC0000u);
     bad += expect("angular dot", bits(dot), 0x439A0000u);
     bad += expect("angular norm", bits(norm), 0x44A18000u);
+
+    /* The same Quadbox and triangle cases as tiled segments (one buffer per segment, [tile][word][RT_DP_TILE_OPS]), three ops each:
+     * op 1 is the case above, ops 0 and 2 are a box the ray enters at t = 2 in child 1 only, resp. zero padding. */
+    enum { N = 3 };
+    static float box_in[RT_DP_TILE_OPS * RT_DP_BOX_TILE_IN_WORDS], tri_in[RT_DP_TILE_OPS * RT_DP_TRI_TILE_IN_WORDS];
+    static uint32_t box_out[RT_DP_TILE_OPS * RT_DP_BOX_TILE_OUT_WORDS], tri_out[RT_DP_TILE_OPS * RT_DP_TRI_TILE_OUT_WORDS];
+    memset(box_out, 0x5A, sizeof box_out);
+    memset(tri_out, 0x5A, sizeof tri_out);
+    for (int i = 0; i < N; ++i) {
+        for (int w = 0; w < 3; ++w) {                                                   /* org, dir, inv */
+            box_in[RT_DP_TILED_INDEX(i, w, RT_DP_BOX_TILE_IN_WORDS)] = 0.0f;
+            box_in[RT_DP_TILED_INDEX(i, 3 + w, RT_DP_BOX_TILE_IN_WORDS)] = 1.0f;
+            box_in[RT_DP_TILED_INDEX(i, 6 + w, RT_DP_BOX_TILE_IN_WORDS)] = 1.0f;
+        }
+        box_in[RT_DP_TILED_INDEX(i, 9, RT_DP_BOX_TILE_IN_WORDS)] = 4000.0f;             /* extent */
+        for (int w = 10; w < 34; ++w) box_in[RT_DP_TILED_INDEX(i, w, RT_DP_BOX_TILE_IN_WORDS)] = INFINITY;
+        for (int w = 0; w < 3; ++w) tri_in[RT_DP_TILED_INDEX(i, w, RT_DP_TRI_TILE_IN_WORDS)] = 0.0f;
+        for (int w = 3; w < 6; ++w) tri_in[RT_DP_TILED_INDEX(i, w, RT_DP_TRI_TILE_IN_WORDS)] = 1.0f;
+        for (int w = 6; w < 15; ++w) tri_in[RT_DP_TILED_INDEX(i, w, RT_DP_TRI_TILE_IN_WORDS)] = 0.0f;
+        memcpy(&tri_in[RT_DP_TILED_INDEX(i, 15, RT_DP_TRI_TILE_IN_WORDS)], &k, 4);
+    }
+    /* op 0: child 1 = [2, 3]^3: tmin = 2, tmax = 3, the only hit.  Keys (Inf, 2, Inf, Inf) through the network (0,2) (1,3) (0,1) (2,3)
+     * (1,2), larger key to the lower position, ties stay: only (1,3) swaps, giving children 0, 3, 2, 1 largest first; the output is that
+     * reversed: 1, 2, 3, 0 (UnifiedDatapath.scala:1117-1132) */
+    for (int f = 0; f < 3; ++f) {
+        box_in[RT_DP_TILED_INDEX(0, 10 + 6 * 1 + f, RT_DP_BOX_TILE_IN_WORDS)] = 2.0f;
+        box_in[RT_DP_TILED_INDEX(0, 10 + 6 * 1 + 3 + f, RT_DP_BOX_TILE_IN_WORDS)] = 3.0f;
+    }
+    rt_dp_op_batch tin;
+    rt_dp_result_batch tout;
+    memset(&tin, 0, sizeof tin);
+    memset(&tout, 0, sizeof tout);
+    tin.struct_size = sizeof tin;
+    tout.struct_size = sizeof tout;
+    tin.flags = RT_DP_F_BOX_TILED | RT_DP_F_TRI_TILED;
+    tin.n[RT_DP_OP_QUADBOX] = N;
+    tin.n[RT_DP_OP_TRIANGLE] = N;
+    tin.box.org[0] = box_in;
+    tout.box.tmin_out[0] = (float *)box_out;
+    tin.tri.org[0] = tri_in;
+    tout.tri.t_num = (float *)tri_out;
+    rc = rt_dp_eval(&tin, &tout);
+    if (rc != RT_DP_OK) {
+        printf("rt_dp_eval (tiled) failed: %d (%s)\n", rc, rt_dp_last_error());
+        return 2;
+    }
+    for (int i = 1; i < N; ++i) {
+        for (int w = 0; w < 4; ++w) bad += expect("tiled tmin_out", box_out[RT_DP_TILED_INDEX(i, w, RT_DP_BOX_TILE_OUT_WORDS)], 0x7F800000u);
+        bad += expect("tiled box flags", box_out[RT_DP_TILED_INDEX(i, 4, RT_DP_BOX_TILE_OUT_WORDS)], (3u << 4) | (2u << 6) | (1u << 8) | (0u << 10));
+    }
+    bad += expect("tiled tmin_out[0] of the hit", box_out[RT_DP_TILED_INDEX(0, 0, RT_DP_BOX_TILE_OUT_WORDS)], 0x40000000u);
+    for (int w = 1; w < 4; ++w) bad += expect("tiled tmin_out of the misses", box_out[RT_DP_TILED_INDEX(0, w, RT_DP_BOX_TILE_OUT_WORDS)], 0x7F800000u);
+    bad += expect("tiled box flags of the hit (isIntersect 0001, boxIndex 1,2,3,0)", box_out[RT_DP_TILED_INDEX(0, 4, RT_DP_BOX_TILE_OUT_WORDS)],
+                  1u | (1u << 4) | (2u << 6) | (3u << 8) | (0u << 10));
+    for (int i = 0; i < N; ++i) {
+        bad += expect("tiled t_num", tri_out[RT_DP_TILED_INDEX(i, 0, RT_DP_TRI_TILE_OUT_WORDS)], 0u);
+        bad += expect("tiled t_denom", tri_out[RT_DP_TILED_INDEX(i, 1, RT_DP_TRI_TILE_OUT_WORDS)], 0u);
+        bad += expect("tiled triangle_hit", tri_out[RT_DP_TILED_INDEX(i, 2, RT_DP_TRI_TILE_OUT_WORDS)], 0u);
+    }
+    bad += expect("word behind op N - 1 of the tiled result buffer", box_out[RT_DP_TILED_INDEX(N, 0, RT_DP_BOX_TILE_OUT_WORDS)], 0x5A5A5A5Au);
     printf(bad ? "KAT FAILED\n" : "KAT OK (%s)\n", rt_dp_version());
     return bad ? 1 : 0;
 }

@@ -67,8 +67,8 @@ enum rt_dp_status {
                                     may be NULL, tri.dir[] is read instead.  12 B (box) and 4 B (triangle)
                                     less traffic per op; results equal those of the two-step path bit for
                                     bit */
-#define RT_DP_F_BOX_TILED   0x4u /* the Quadbox segment is in tiled form (below); needs RT_DP_F_DEVICE_PTRS */
-#define RT_DP_F_TRI_TILED   0x8u /* the triangle segment is in tiled form; needs RT_DP_F_DEVICE_PTRS */
+#define RT_DP_F_BOX_TILED   0x4u /* the Quadbox segment is in tiled form (below) */
+#define RT_DP_F_TRI_TILED   0x8u /* the triangle segment is in tiled form */
 #define RT_DP_F_ALL_FLAGS   0xFu
 
 /* ---- tiled segments ---------------------------------------------------------
@@ -84,7 +84,8 @@ enum rt_dp_status {
  *   triangle operands (16): org xyz, shear xyz, A xyz, B xyz, C xyz, k; passed in tri.org[0]
  *   triangle results   (3): t_num, t_denom, hit; passed in tri.t_num
  * Under RT_DP_F_DERIVE_RAY the inv words (box) and the k word (triangle) are not read, and the shear words hold
- * the ray direction.  Results are the same bits as those of the plain form.  No counterpart in the reference: its
+ * the ray direction.  Host buffers work as well (without RT_DP_F_DEVICE_PTRS): a tiled segment then crosses the
+ * link in one copy each way instead of one per operand array.  Results are the same bits as those of the plain form.  No counterpart in the reference: its
  * testbench pokes one record per cycle (Datapath_test.scala:275-302).                                          */
 #define RT_DP_TILE_OPS            8192u
 #define RT_DP_BOX_TILE_IN_WORDS   34u

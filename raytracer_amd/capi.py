@@ -231,6 +231,15 @@ def _ptr(x, kinds):
     return x.ctypes.data
 
 
+def _words(x):
+    """Number of elements of a buffer of 32-bit words (torch tensor or numpy array)."""
+    if _is_torch(x):
+        assert x.element_size() == 4
+        return x.numel()
+    assert x.itemsize == 4
+    return x.size
+
+
 class Batch:
     """Builder for one rt_dp_op_batch / rt_dp_result_batch pair.  Keeps every array alive."""
 
@@ -285,18 +294,18 @@ class Batch:
         self.ob.n[OP_TRIANGLE] = int(fields[0].shape[0]) if n is None else int(n)
 
     def set_box_tiled(self, operands, results, n):
-        """RT_DP_F_BOX_TILED: operands / results are CUDA tensors of tiled_words(n, 34) / tiled_words(n, 5) 32-bit words."""
-        assert operands.numel() >= tiled_words(n, BOX_TILE_IN_WORDS) and results.numel() >= tiled_words(n, BOX_TILE_OUT_WORDS)
-        assert operands.element_size() == 4 and results.element_size() == 4
+        """RT_DP_F_BOX_TILED: operands / results are buffers (CUDA tensors or numpy arrays) of tiled_words(n, 34) /
+        tiled_words(n, 5) 32-bit words."""
+        assert _words(operands) >= tiled_words(n, BOX_TILE_IN_WORDS) and _words(results) >= tiled_words(n, BOX_TILE_OUT_WORDS)
         self.ob.box.org[0] = self._p(operands)
         self.rb.box.tmin_out[0] = self._p(results)
         self.ob.n[OP_QUADBOX] = int(n)
         self._tiled |= F_BOX_TILED
 
     def set_tri_tiled(self, operands, results, n):
-        """RT_DP_F_TRI_TILED: operands / results are CUDA tensors of tiled_words(n, 16) / tiled_words(n, 3) 32-bit words."""
-        assert operands.numel() >= tiled_words(n, TRI_TILE_IN_WORDS) and results.numel() >= tiled_words(n, TRI_TILE_OUT_WORDS)
-        assert operands.element_size() == 4 and results.element_size() == 4
+        """RT_DP_F_TRI_TILED: operands / results are buffers (CUDA tensors or numpy arrays) of tiled_words(n, 16) /
+        tiled_words(n, 3) 32-bit words."""
+        assert _words(operands) >= tiled_words(n, TRI_TILE_IN_WORDS) and _words(results) >= tiled_words(n, TRI_TILE_OUT_WORDS)
         self.ob.tri.org[0] = self._p(operands)
         self.rb.tri.t_num = self._p(results)
         self.ob.n[OP_TRIANGLE] = int(n)

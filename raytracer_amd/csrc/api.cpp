@@ -116,8 +116,6 @@ int check_batch(const rt_dp_op_batch *in, const rt_dp_result_batch *out) {
     } while (0)
 
     const bool derive = (in->flags & RT_DP_F_DERIVE_RAY) != 0;
-    if ((in->flags & (RT_DP_F_BOX_TILED | RT_DP_F_TRI_TILED)) && !(in->flags & RT_DP_F_DEVICE_PTRS))
-        return fail(RT_DP_EINVAL, "tiled segments need device pointers (RT_DP_F_DEVICE_PTRS)");
     if (in->n[RT_DP_OP_TRIANGLE] && (in->flags & RT_DP_F_TRI_TILED)) {
         NEED(in->tri.org[0], "tri.org[0] (the tiled operand buffer)");
         NEED(out->tri.t_num, "result tri.t_num (the tiled result buffer)");
@@ -326,7 +324,25 @@ int eval_host(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *out)
     const uint64_t n_tri = in->n[RT_DP_OP_TRIANGLE], n_box = in->n[RT_DP_OP_QUADBOX];
     const uint64_t n_euc = in->n[RT_DP_OP_EUCLIDEAN], n_ang = in->n[RT_DP_OP_ANGULAR];
     const bool derive = (in->flags & RT_DP_F_DERIVE_RAY) != 0;
-    if (n_tri) {
+    // A tiled segment is one buffer each way.  The operands are copied whole (the buffer spans whole tiles); of the results
+    // everything up to the last tile is copied back in one piece and the last tile word by word, so that what lies behind
+    // op n - 1 in the caller's buffer stays as it was.
+    auto tiled_out = [&](void **field, void *host, uint64_t n, uint32_t words) {
+        const uint64_t full = (n - 1) / kTileOps, rem = n - full * kTileOps;  // tiles in front of the last one, ops in the last one
+        char *h = static_cast<char *>(host);
+        const size_t base = out_total;
+        fix_out.push_back({field, base});
+        if (full) outs.push_back({nullptr, h, (size_t)(full * words * kTileOps * 4), base});
+        for (uint32_t w = 0; w < words; ++w) {
+            const size_t o = (size_t)((full * words + w) * kTileOps * 4);
+            outs.push_back({nullptr, h + o, (size_t)(rem * 4), base + o});
+        }
+        out_total += align_up((size_t)((full + 1) * words * kTileOps * 4));
+    };
+    if (n_tri && (in->flags & RT_DP_F_TRI_TILED)) {
+        IN_ARR(din.tri.org[0], RT_DP_TILED_WORDS(n_tri, RT_DP_TRI_TILE_IN_WORDS), 4);
+        tiled_out(reinterpret_cast<void **>(&dout.tri.t_num), out->tri.t_num, n_tri, RT_DP_TRI_TILE_OUT_WORDS);
+    } else if (n_tri) {
         for (int a = 0; a < 3; ++a) {
             IN_ARR(din.tri.org[a], n_tri, 4);
             if (derive) IN_ARR(din.tri.dir[a], n_tri, 4);
@@ -337,7 +353,10 @@ int eval_host(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *out)
         if (!derive) IN_ARR(din.tri.k, n_tri, 4);
         OUT_ARR(dout.tri.t_num, n_tri, 4); OUT_ARR(dout.tri.t_denom, n_tri, 4); OUT_ARR(dout.tri.hit, n_tri, 4);
     }
-    if (n_box) {
+    if (n_box && (in->flags & RT_DP_F_BOX_TILED)) {
+        IN_ARR(din.box.org[0], RT_DP_TILED_WORDS(n_box, RT_DP_BOX_TILE_IN_WORDS), 4);
+        tiled_out(reinterpret_cast<void **>(&dout.box.tmin_out[0]), out->box.tmin_out[0], n_box, RT_DP_BOX_TILE_OUT_WORDS);
+    } else if (n_box) {
         for (int a = 0; a < 3; ++a) {
             IN_ARR(din.box.org[a], n_box, 4);
             IN_ARR(din.box.dir[a], n_box, 4);

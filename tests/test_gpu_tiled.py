@@ -259,9 +259,6 @@ def test_tiled_argument_errors(ctx, torch_cuda):
     b = capi.Batch()
     b.set_box_tiled(operands, results, n)
     b.finalize()
-    b.ob.flags &= ~capi.F_DEVICE_PTRS                     # tiled segments are device buffers
-    assert L.rt_dp_eval_ctx(ctx._h, C.byref(b.ob), C.byref(b.rb)) == capi.EINVAL
-    b.ob.flags |= capi.F_DEVICE_PTRS
     b.rb.box.tmin_out[0] = None
     assert L.rt_dp_eval_ctx(ctx._h, C.byref(b.ob), C.byref(b.rb)) == capi.ENULL
     ptrs = (C.c_void_p * 41)(*([operands.data_ptr()] * 41))
@@ -308,3 +305,39 @@ def test_compaction_over_a_tiled_result_buffer(ctx, oracle, torch_cuda, n, table
     assert np.array_equal(oc.cpu().numpy().view(u32)[:count], want_c)
     if tables:
         assert np.array_equal(ot.cpu().numpy().view(u32)[:count], want_t.view(u32))
+
+
+@pytest.mark.parametrize("n", [1, 300, T, T + 1, 3 * T + 17])
+def test_tiled_segments_in_host_buffers(ctx, oracle, n):
+    """Without RT_DP_F_DEVICE_PTRS the library stages a tiled segment in one copy each way; the bytes behind op n - 1 of the
+    caller's result buffers stay as they were."""
+    bf = [np.ascontiguousarray(f) for f in gen.box_ops(n, seed=61 + n, edge_frac=0.2)]
+    tf, tk = gen.tri_ops(n, seed=62 + n, edge_frac=0.2)
+    tf = [np.ascontiguousarray(f) for f in tf]
+    box_in, tri_in = pack_numpy(bf), pack_numpy(tf + [tk])
+    box_out = np.full(capi.tiled_words(n, 5), SENTINEL, u32)
+    tri_out = np.full(capi.tiled_words(n, 3), SENTINEL, u32)
+    a, bb, ctl, _ = gen.vec_beats(50, 16, seed=63)
+    acc = np.zeros(ctl.shape[0], f32)
+    b = capi.Batch()
+    b.set_box_tiled(box_in, box_out, n)
+    b.set_tri_tiled(tri_in, tri_out, n)
+    b.set_euclid(a, bb, ctl, acc)
+    ctx.reset()
+    ctx.eval(b)
+    want_t, want_f = oracle.box_soa(bf)
+    got = unpack_numpy(box_out, 5, n)
+    for k in range(4):
+        assert_bits_equal(got[k], want_t[k], "tmin_out[%d]" % k)
+    assert_bits_equal(got[4], want_f, "flags")
+    wn, wd, wh = oracle.tri_soa(tf, tk)
+    got = unpack_numpy(tri_out, 3, n)
+    assert_bits_equal(got[0], wn, "t_num")
+    assert_bits_equal(got[1], wd, "t_denom")
+    assert_bits_equal(got[2], wh, "hit")
+    assert_bits_equal(acc, oracle.euclid_beats(a, bb, ctl)[0], "euclidean beats next to the tiled segments")
+    for raw, words in ((box_out, 5), (tri_out, 3)):
+        mask = np.ones(raw.shape[0], bool)
+        for w in range(words):
+            mask[tile_index(np.arange(n), w, words)] = False
+        assert (raw[mask] == SENTINEL).all(), "bytes behind op n - 1 of a host result buffer were overwritten"
