@@ -40,17 +40,6 @@ def unpack_numpy(tiled, words, n):
     return [tiled[tile_index(idx, k, words)] for k in range(words)]
 
 
-def test_the_index_macro_and_the_python_size_helper_agree_with_the_header():
-    # RT_DP_TILED_WORDS / RT_DP_TILED_INDEX, restated: whole tiles, word-major inside a tile
-    assert capi.tiled_words(1, 34) == 34 * T and capi.tiled_words(T, 5) == 5 * T and capi.tiled_words(T + 1, 3) == 6 * T
-    assert capi.tiled_words(0, 34) == 0
-    assert tile_index(0, 0, 34) == 0 and tile_index(1, 0, 34) == 1 and tile_index(0, 1, 34) == T
-    assert tile_index(T, 0, 34) == 34 * T and tile_index(T + 5, 33, 34) == 34 * T + 33 * T + 5
-    with open(__file__.rsplit("/tests/", 1)[0] + "/include/rt_dp.h") as f:
-        text = f.read()
-    assert "#define RT_DP_TILE_OPS            %du" % T in text
-
-
 @pytest.mark.parametrize("n", SIZES)
 @pytest.mark.parametrize("words", [1, 5, 34, 40])
 def test_pack_and_unpack_follow_the_layout(ctx, torch_cuda, n, words):
