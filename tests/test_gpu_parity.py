@@ -412,13 +412,13 @@ def test_device_record_stream_carries_accumulators(oracle, torch_cuda, mode):
     c.close()
 
 
-def _single_pass_case(oracle, torch, stream, what, chunk_log2=None, monkeypatch=None):
+def _single_pass_case(oracle, torch, stream, what, chunk_log2=None, monkeypatch=None, mode=3):
     """One stream through the single-pass record-stream kernel against oracle B, registers included, twice in a row on one
     context (the second call continues the first one's registers)."""
     if chunk_log2 is not None:
         monkeypatch.setenv("RT_DP_STREAM_CHUNK_LOG2", str(chunk_log2))
     c = capi.Context()
-    c.set_option("stream_mode", 3)
+    c.set_option("stream_mode", mode)
     two = np.ascontiguousarray(np.concatenate([stream, stream]))
     want, state = oracle.eval_bundles("B", two.view(oracle.IN_BUNDLE).reshape(-1), extended=True)
     want = want.view(u32).reshape(-1, 21)
@@ -482,7 +482,29 @@ def test_single_pass_record_stream_corner_streams(oracle, torch_cuda, kind):
     _single_pass_case(oracle, torch, np.ascontiguousarray(stream), kind)
 
 
-def test_single_pass_record_stream_in_pieces(oracle, torch_cuda, monkeypatch):
+@pytest.mark.parametrize("mode", [2, 3])
+def test_record_stream_in_pieces(oracle, torch_cuda, monkeypatch, mode):
     """Pieces of 2^11 records inside one call: the registers travel from piece to piece on the device."""
     stream = _mixed_stream(91, 4000, 4000, 600, 600)
-    _single_pass_case(oracle, torch_cuda, stream, "2^11-record pieces", chunk_log2=11, monkeypatch=monkeypatch)
+    _single_pass_case(oracle, torch_cuda, stream, "2^11-record pieces", chunk_log2=11, monkeypatch=monkeypatch, mode=mode)
+
+
+def test_record_stream_pieces_no_reset_and_bad_opcode(oracle, torch_cuda, monkeypatch):
+    """Pieces of one call on a stream whose pairs never end (every piece depends on the one before), and on a stream with an
+    opcode > 3 in a late piece: the error is reported and the registers keep their values."""
+    torch = torch_cuda
+    base = _mixed_stream(92, 3000, 3000, 700, 700)
+    endless = base.copy()
+    endless[endless[:, 0] >= 2, 83] = 0
+    _single_pass_case(oracle, torch, np.ascontiguousarray(endless), "endless pairs in 2^11-record pieces", chunk_log2=11, monkeypatch=monkeypatch, mode=2)
+    c = capi.Context()
+    c.set_option("stream_mode", 2)
+    c.set_accum([1.5, -2.5, 3.5])
+    bad = base.copy()
+    bad[-5, 0] = 6
+    d_out = torch.empty((bad.shape[0], 21), dtype=torch.int32, device="cuda")
+    with pytest.raises(capi.RtDpError) as e:
+        c.eval_bundles_device(torch.from_numpy(bad.view(np.int32)).cuda(), d_out)
+    assert e.value.code == capi.EOPCODE
+    assert_bits_equal(c.get_accum(), np.array([1.5, -2.5, 3.5], f32), "registers after a refused stream")
+    c.close()
