@@ -44,6 +44,7 @@ struct rt_dp_ctx {
     int device = 0;
     bool extended = true;  // support_euclidean == Some(16)
     hipStream_t stream = nullptr;
+    unsigned long long *h_words = nullptr;  // 8 pinned host words: small read-backs (flags, counts) land here without a staging copy
     // accumulator registers live in HBM; two copies so that the workgroup that
     // reads the incoming value never races the one that writes the outgoing one
     // The accumulator registers, [3][4] floats: {euclid, dot, norm, pad}; copy 2 is a call's backup.  A beat kernel reads its
@@ -199,6 +200,15 @@ int join_caller_stream(rt_dp_ctx *ctx, bool host_too) {
         HIP_TRY(hipEventSynchronize(ctx->launched));
         ctx->launched_pending = false;
     }
+    return RT_DP_OK;
+}
+
+// Pinned landing place of small device-to-host read-backs (a copy into pageable memory goes through a staging buffer of the
+// runtime and costs several microseconds more).
+int pinned_words(rt_dp_ctx *ctx) {
+    if (ctx->h_words) return RT_DP_OK;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_words), 8 * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e != hipSuccess) return fail(RT_DP_ENOMEM, "hipHostMalloc(64) failed: %s", hipGetErrorString(e));
     return RT_DP_OK;
 }
 
@@ -521,6 +531,7 @@ void rt_dp_destroy(rt_dp_ctx *ctx) {
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->d_chain) (void)hipFree(ctx->d_chain);
     for (char *old_chain : ctx->chain_retired) (void)hipFree(old_chain);
+    if (ctx->h_words) (void)hipHostFree(ctx->h_words);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (g_default_ctx.p == ctx) g_default_ctx.p = nullptr;
     delete ctx;
@@ -666,7 +677,19 @@ int rt_dp_set_tuning(rt_dp_ctx *ctx, int ops_per_lane, int nontemporal, int vec_
 }
 
 // Record stream resident in HBM: partition, evaluate and re-assemble on the device.
+// ordered: the records were produced on the context's own stream (no wait for the rest of the device needed).
+// pinned_out: when the fused path runs, the output records are also copied to this pinned host buffer in front of the
+// call's one synchronisation, and *copied says so.
+static int bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt_dp_output_bundle *d_out, uint64_t n, bool ordered, void *pinned_out,
+                          bool *copied);
+
 int rt_dp_eval_bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt_dp_output_bundle *d_out, uint64_t n) {
+    return bundles_device(ctx, d_in, d_out, n, false, nullptr, nullptr);
+}
+
+static int bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt_dp_output_bundle *d_out, uint64_t n, bool ordered, void *pinned_out,
+                          bool *copied) {
+    if (copied) *copied = false;
     if (!ctx) return fail(RT_DP_ENULL, "rt_dp_eval_bundles_device: ctx is NULL");
     if (n == 0) return RT_DP_OK;
     if (!d_in || !d_out) return fail(RT_DP_ENULL, "rt_dp_eval_bundles_device: in/out is NULL");
@@ -675,7 +698,13 @@ int rt_dp_eval_bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
     hipStream_t s = ctx->stream;
-    HIP_TRY(hipDeviceSynchronize());  // the records may still be in production on a caller stream
+    if (ordered) {  // the records are on the context's stream; the registers may have been left by a batch on a caller stream
+        int rcj = join_caller_stream(ctx, false);
+        if (rcj != RT_DP_OK) return rcj;
+    } else {
+        HIP_TRY(hipDeviceSynchronize());  // the records may still be in production on a caller stream
+        ctx->launched_pending = false;
+    }
 
     auto grow = [&](char *&buf, size_t &have, size_t want) -> int {
         if (want <= have) return RT_DP_OK;
@@ -716,8 +745,14 @@ int rt_dp_eval_bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt
                                       ctx->d_state + 4 * (c ^ 1), &sticky, s));
             if (ctx->extended) c ^= 1;
         }
-        unsigned long long seen[2] = {0, 0};  // {give-ups, opcode > 3}
-        HIP_TRY(hipMemcpyAsync(seen, sticky, sizeof seen, hipMemcpyDeviceToHost, s));
+        rc = pinned_words(ctx);
+        if (rc != RT_DP_OK) return rc;
+        unsigned long long *seen = ctx->h_words;  // {give-ups, opcode > 3}
+        if (pinned_out) {
+            HIP_TRY(hipMemcpyAsync(pinned_out, d_out, n * sizeof(rt_dp_output_bundle), hipMemcpyDeviceToHost, s));
+            *copied = true;
+        }
+        HIP_TRY(hipMemcpyAsync(seen, sticky, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         const bool bad = seen[1] != 0;
         ctx->stream_giveups += seen[0];
@@ -752,25 +787,31 @@ int rt_dp_eval_bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt
         if (ctx->extended && home_e != home_a)
             HIP_TRY(hipMemcpyAsync(ctx->d_state + 4 * home_a, ctx->d_state + 4 * home_e, sizeof(float), hipMemcpyDeviceToDevice, s));
         int c = home_a;
-        HIP_TRY(hipMemcpyAsync(ctx->d_state + 8, ctx->d_state + 4 * c, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));  // backup
-        HIP_TRY(stream_fused_begin(ctx->d_stream, first, s));
+        // A fold reads the registers from one copy and writes all three into the other, so a call of one piece leaves the copy
+        // it started from intact; only a call of several pieces needs the backup for the case that it is refused.
+        const bool one_piece = n <= chunk;
+        if (ctx->extended && !one_piece)
+            HIP_TRY(hipMemcpyAsync(ctx->d_state + 8, ctx->d_state + 4 * c, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
         for (uint64_t off = 0; off < n; off += chunk) {
             const uint64_t m = (n - off < chunk) ? (n - off) : chunk;
-            HIP_TRY(stream_fused_eval(in_words + off * 84, m, first, ctx->extended ? 1 : 0, out_words + off * 21, ctx->d_stream, &view, s));
+            HIP_TRY(stream_fused_eval(in_words + off * 84, m, first, ctx->extended ? 1 : 0, out_words + off * 21, ctx->d_stream, &view, s, off == 0));
             if (ctx->extended) {
-                float *cur = ctx->d_state + 4 * c, *nxt = ctx->d_state + 4 * (c ^ 1);
-                // registers of an opcode without beats in this piece are carried over unchanged
-                HIP_TRY(hipMemcpyAsync(nxt, cur, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
-                HIP_TRY(stream_fused_fold(view, m, cur, nxt, out_words + off * 21, s));
+                HIP_TRY(stream_fused_fold(view, m, ctx->d_state + 4 * c, ctx->d_state + 4 * (c ^ 1), out_words + off * 21, s));
                 c ^= 1;
             }
         }
-        uint32_t bad = 0;
-        HIP_TRY(hipMemcpyAsync(&bad, view.flags + 8, sizeof bad, hipMemcpyDeviceToHost, s));
+        rc = pinned_words(ctx);
+        if (rc != RT_DP_OK) return rc;
+        if (pinned_out) {
+            HIP_TRY(hipMemcpyAsync(pinned_out, d_out, n * sizeof(rt_dp_output_bundle), hipMemcpyDeviceToHost, s));
+            *copied = true;
+        }
+        HIP_TRY(hipMemcpyAsync(ctx->h_words, view.flags + 8, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        const uint32_t bad = *reinterpret_cast<const uint32_t *>(ctx->h_words);
         if (bad) {  // the registers keep their values from before the call
             c = home_a;
-            HIP_TRY(hipMemcpy(ctx->d_state + 4 * c, ctx->d_state + 8, 4 * sizeof(float), hipMemcpyDeviceToDevice));
+            if (ctx->extended && !one_piece) HIP_TRY(hipMemcpy(ctx->d_state + 4 * c, ctx->d_state + 8, 4 * sizeof(float), hipMemcpyDeviceToDevice));
         }
         if (ctx->extended) {
             // all three registers are in copy c now; a register whose address a graph holds goes back to that address
@@ -1442,6 +1483,23 @@ int rt_dp_eval_bundles(rt_dp_ctx *ctx, const rt_dp_input_bundle *in, rt_dp_outpu
     if (rc != RT_DP_OK) return rc;
     rt_dp_input_bundle *d_in = reinterpret_cast<rt_dp_input_bundle *>(ctx->d_records);
     rt_dp_output_bundle *d_out = reinterpret_cast<rt_dp_output_bundle *>(ctx->d_records + cap * sizeof(rt_dp_input_bundle));
+    if (n * (sizeof(rt_dp_input_bundle) + sizeof(rt_dp_output_bundle)) <= kPinnedStage) {
+        // Small streams (the testbench's suites are 100 records) are bound by latency: the records cross the link through a
+        // pinned mirror, in and out on the context's stream, and the call synchronises once.
+        if (!ctx->h_stage) {
+            hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_stage), kPinnedStage, hipHostMallocDefault);
+            if (e != hipSuccess) return fail(RT_DP_ENOMEM, "hipHostMalloc(%zu) for staging failed: %s", kPinnedStage, hipGetErrorString(e));
+        }
+        const size_t in_bytes = n * sizeof(rt_dp_input_bundle), out_bytes = n * sizeof(rt_dp_output_bundle);
+        memcpy(ctx->h_stage, in, in_bytes);
+        HIP_TRY(hipMemcpyAsync(d_in, ctx->h_stage, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+        bool copied = false;
+        rc = bundles_device(ctx, d_in, d_out, n, true, ctx->h_stage + align_up(in_bytes), &copied);
+        if (rc != RT_DP_OK) return rc;
+        if (copied) memcpy(out, ctx->h_stage + align_up(in_bytes), out_bytes);
+        else HIP_TRY(hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost));
+        return RT_DP_OK;
+    }
     for (uint64_t off = 0; off < n; off += piece) {
         const uint64_t m = (n - off < piece) ? (n - off) : piece;
         HIP_TRY(hipMemcpy(d_in, in + off, m * sizeof(rt_dp_input_bundle), hipMemcpyHostToDevice));

@@ -102,9 +102,8 @@ struct StreamSideView {
     const uint32_t *flags;  // [1] opcode 2 present, [2] opcode 3 present (per launch); [8] opcode > 3 seen (sticky, cleared by the caller)
 };
 size_t stream_fused_workspace(uint64_t capacity);
-hipError_t stream_fused_begin(char *workspace, uint64_t capacity, hipStream_t s);
 hipError_t stream_fused_eval(const uint32_t *in, uint64_t n, uint64_t capacity, int extended, uint32_t *out, char *workspace,
-                             StreamSideView *view, hipStream_t s);
+                             StreamSideView *view, hipStream_t s, bool first_piece = false);
 hipError_t stream_fused_fold(const StreamSideView &v, uint64_t n, const float *state_in, float *state_out, uint32_t *out, hipStream_t s);
 // the same in one pass (running sums handed from wave to wave); state_in / state_out: {euclid, dot, norm}
 size_t stream_chain_workspace(uint64_t capacity);

@@ -393,13 +393,17 @@ __device__ __forceinline__ void stream_fold(const uint32_t *__restrict__ tag, co
 }
 
 // blockIdx.y = 0: Euclidean, 1: angular, side by side in one launch; an opcode that does not occur in
-// the stream (flags written by k_stream_eval) costs one load per workgroup.  state: {euclid, dot, norm}.
+// the stream (flags written by k_stream_eval) costs one load per workgroup.  state: {euclid, dot, norm}; state_out is
+// written completely: by the workgroup that owns the last record of an opcode that occurs, and as a copy of state_in
+// for an opcode that does not.
 __global__ __launch_bounds__(kFoldThreads) void k_stream_fold(StreamSideView v, uint64_t n, uint32_t tile, const float *__restrict__ state_in,
                                                      float *__restrict__ state_out, uint32_t *__restrict__ out) {
     if (blockIdx.y == 0) {
         if (v.flags[1]) stream_fold<true>(v.tag, v.sum0, v.sum1, v.rbits[0], n, tile, state_in, state_out, out);
+        else if (blockIdx.x == 0 && threadIdx.x == 0) state_out[0] = state_in[0];
     } else {
         if (v.flags[2]) stream_fold<false>(v.tag, v.sum0, v.sum1, v.rbits[1], n, tile, state_in + 1, state_out + 1, out);
+        else if (blockIdx.x == 0 && threadIdx.x == 0) { state_out[1] = state_in[1]; state_out[2] = state_in[2]; }
     }
 }
 
@@ -643,20 +647,14 @@ size_t stream_fused_workspace(uint64_t capacity) {
     return static_cast<size_t>(reinterpret_cast<char *>(side.flags) - static_cast<char *>(nullptr)) + 256;
 }
 
-// Clears the sticky "opcode > 3" word; once per call, before the first piece.
-hipError_t stream_fused_begin(char *workspace, uint64_t capacity, hipStream_t s) {
-    const StreamSide side = stream_fused_layout(workspace, capacity, nullptr);
-    return hipMemsetAsync(side.flags, 0, 256, s);
-}
-
-// One piece of n <= capacity records.
+// One piece of n <= capacity records.  first_piece: also clears the sticky "opcode > 3" word, once per call.
 hipError_t stream_fused_eval(const uint32_t *in, uint64_t n, uint64_t capacity, int extended, uint32_t *out, char *workspace,
-                             StreamSideView *view, hipStream_t s) {
+                             StreamSideView *view, hipStream_t s, bool first_piece) {
     size_t bits = 0;
     const StreamSide side = stream_fused_layout(workspace, capacity, &bits);
     const uint64_t nblk = (n + 63) / 64;
     if (n > capacity || nblk > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(side.rbits[0], 0, bits + 32, s);  // both bit arrays and the per-piece flags
+    hipError_t e = hipMemsetAsync(side.rbits[0], 0, bits + (first_piece ? 256 : 32), s);  // both bit arrays and the per-piece flags (all flags on the first piece)
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_stream_eval, dim3((unsigned)nblk), dim3(64), 0, s, in, n, extended, out, side);
     view->tag = side.tag; view->sum0 = side.sum0; view->sum1 = side.sum1;
