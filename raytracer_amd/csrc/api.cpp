@@ -212,6 +212,16 @@ int pinned_words(rt_dp_ctx *ctx) {
     return RT_DP_OK;
 }
 
+// Up to 64 bytes from device memory into *dst through the pinned words; synchronises s.
+int read_back(rt_dp_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t s) {
+    int rc = pinned_words(ctx);
+    if (rc != RT_DP_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->h_words, src, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    memcpy(dst, ctx->h_words, bytes);
+    return RT_DP_OK;
+}
+
 // The chained beat kernels' workspace for a segment of n beats and a fresh epoch, on stream s.
 int chain_for(rt_dp_ctx *ctx, uint64_t n, hipStream_t s, VecArgs &a) {
     const size_t need = vec_chain_bytes(n);
@@ -834,8 +844,8 @@ static int bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt_dp_
 
     HIP_TRY(stream_count_scan(in_words, n, blockcnt, totals, s));
     uint32_t h[8];
-    HIP_TRY(hipMemcpyAsync(h, totals, sizeof h, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    rc = read_back(ctx, h, totals, sizeof h, s);
+    if (rc != RT_DP_OK) return rc;
     if (h[4]) return fail(RT_DP_EOPCODE, "the record stream holds an opcode > 3; the RTL's opcode field is 2 bits wide");
     const uint64_t nt = h[0], nb = h[1], ne = h[2], na = h[3];
 
@@ -1191,10 +1201,11 @@ static int box_compact(const char *who, rt_dp_ctx *ctx, const uint32_t *flags, c
     unsigned long long *offsets64 = reinterpret_cast<unsigned long long *>(ctx->d_trace + o_off);
     unsigned long long *total = reinterpret_cast<unsigned long long *>(ctx->d_trace + o_tot);
     HIP_TRY(compact_hits(flags, tm, n, item, children, blockcnt, offsets64, total, capacity, out_item, out_child, out_tmin, s, tile_words));
-    unsigned long long h = 0;
-    HIP_TRY(hipMemcpyAsync(&h, total, sizeof h, hipMemcpyDeviceToHost, s));
+    rc = pinned_words(ctx);
+    if (rc != RT_DP_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->h_words, total, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    *count = h;
+    *count = ctx->h_words[0];
     return RT_DP_OK;
 }
 
@@ -1286,8 +1297,8 @@ int rt_dp_trace_closest(rt_dp_ctx *ctx, const rt_dp_bvh4 *bvh, const float *cons
         uint32_t bad = 0;
         HIP_TRY(hipMemsetAsync(counters, 0, 16, s));
         HIP_TRY(trace_validate(bvh->nodes, bvh->n_nodes, bvh->n_tris, counters, s));
-        HIP_TRY(hipMemcpyAsync(&bad, counters, 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        rc = read_back(ctx, &bad, counters, 4, s);
+        if (rc != RT_DP_OK) return rc;
         if (bad)
             return fail(RT_DP_EINVAL, "node %u holds a child reference outside the hierarchy (inner children must have a larger index than their parent)", bad - 1);
     }
@@ -1297,8 +1308,8 @@ int rt_dp_trace_closest(rt_dp_ctx *ctx, const rt_dp_bvh4 *bvh, const float *cons
         HIP_TRY(hipMemsetAsync(counters, 0, 32, s));
         HIP_TRY(trace_dfs(origin, dir, n_rays, extent, bvh->nodes, bvh->tris, out_t, out_tri, totals, overflow, totals + 3, s));
         unsigned long long host[3];
-        HIP_TRY(hipMemcpyAsync(host, counters, 24, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        rc = read_back(ctx, host, counters, 24, s);
+        if (rc != RT_DP_OK) return rc;
         if (host[2] & 0xFFFFFFFFull) return fail(RT_DP_EINVAL, "a ray had more than 64 pending entries: the hierarchy is too deep for the depth-first walk");
         if (stats) { stats[1] = host[0]; stats[2] = host[1]; }
         return RT_DP_OK;
@@ -1321,8 +1332,8 @@ int rt_dp_trace_closest(rt_dp_ctx *ctx, const rt_dp_bvh4 *bvh, const float *cons
             HIP_TRY(hipMemsetAsync(counters, 0, 16, s));
             HIP_TRY(trace_box(ctx->d_queue[cur], (uint32_t)count, rays, bvh->nodes, best, ctx->d_queue[nxt], (uint32_t)ctx->queue_items[nxt],
                               ctx->d_queue[lf], (uint32_t)ctx->queue_items[lf], counters, s));
-            HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+            rc = read_back(ctx, host, counters, 16, s);
+            if (rc != RT_DP_OK) return rc;
             if (host[0] <= ctx->queue_items[nxt] && host[1] <= ctx->queue_items[lf]) break;
             if (host[0] > ctx->queue_items[nxt]) {
                 size_t bytes = ctx->queue_items[nxt] * 8;
@@ -1340,8 +1351,8 @@ int rt_dp_trace_closest(rt_dp_ctx *ctx, const rt_dp_bvh4 *bvh, const float *cons
         box_ops += count;
         if (host[1]) {
             HIP_TRY(trace_tri(ctx->d_queue[lf], host[1], rays, bvh->tris, best, counters, s));
-            HIP_TRY(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+            rc = read_back(ctx, host, counters, 16, s);
+            if (rc != RT_DP_OK) return rc;
             tri_ops += host[2];
         }
         count = host[0];
