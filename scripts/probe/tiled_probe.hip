@@ -232,6 +232,44 @@ __global__ __launch_bounds__(256) void k_box_stride(const float *__restrict__ in
     __builtin_nontemporal_store(fl, q + 4 * T);
 }
 
+// vector addressing, paced loads; the results of the workgroup's 256 ops go through LDS and out as 16-byte stores (one wave-instruction
+// writes 1 KiB of one result word's run instead of 256 B)
+template <int T>
+__global__ __launch_bounds__(256) void k_tiled_wide_st(const float *__restrict__ in, uint32_t *__restrict__ out, uint64_t n) {
+    __shared__ __align__(16) uint32_t s_res[5 * 256];
+    const uint64_t first = (uint64_t)blockIdx.x * 256u;
+    const uint64_t i = first + threadIdx.x;
+    const uint64_t tile = first / T;
+    const uint32_t w0 = (uint32_t)(first % T);
+    if (i < n) {
+        const float *p = in + tile * (uint64_t)(kBoxFields * T) + w0 + threadIdx.x;
+        float x[kBoxFields];
+#pragma unroll
+        for (int f = 0; f < kBoxFields; ++f) {
+            x[f] = __builtin_nontemporal_load(p + f * T);
+            asm volatile("s_nop 5");
+        }
+        float t[4]; uint32_t fl;
+        box_one(x, t, fl);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_res[k * 256 + threadIdx.x] = __float_as_uint(t[k]);
+        s_res[4 * 256 + threadIdx.x] = fl;
+    }
+    __syncthreads();
+    if (first + 256 <= n) {  // full workgroup: 320 chunks of 16 bytes
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        uint32_t *q = out + tile * (uint64_t)(5 * T) + w0;
+        for (int c = threadIdx.x; c < 320; c += 256) {
+            const int k = c / 64, j = c % 64;   // result word, chunk inside the 1 KiB run
+            __builtin_nontemporal_store(reinterpret_cast<const u4 *>(s_res + k * 256)[j], reinterpret_cast<u4 *>(q + (size_t)k * T) + j);
+        }
+    } else if (i < n) {
+        uint32_t *q = out + tile * (uint64_t)(5 * T) + w0 + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) q[(size_t)k * T] = s_res[k * 256 + threadIdx.x];
+    }
+}
+
 struct Ptrs { const float *in[kBoxFields]; uint32_t *out[5]; };
 __global__ __launch_bounds__(256) void k_plain(Ptrs a, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
@@ -335,24 +373,12 @@ int main(int argc, char **argv) {
 #define BOXRUN(NAME, K) ms = time_ms([&] { hipLaunchKernelGGL(K, dim3(blocks), dim3(256), lds, 0, in, out, n); }, 10, 40); \
             printf("box n 2^%d cap %2d  %-20s %.4f ms frac %.4f\n", lg, w, NAME, ms, n * 156.0 / ms / 1e6 / 8000.0);
             {
-                float *in2; uint32_t *out2;   // room for 40 words in and 8 words out per op
-                CK(hipMalloc(&in2, (n + 8192) * 40 * 4)); CK(hipMalloc(&out2, (n + 8192) * 8 * 4));
-                hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, in2, (n + 8192) * 40, 777u);
-                CK(hipDeviceSynchronize());
-#define SRUN(NAME, K, BYTES) ms = time_ms([&] { hipLaunchKernelGGL(K, dim3(blocks), dim3(256), lds, 0, in2, out2, n); }, 10, 40); \
-                printf("n 2^%d cap %2d  %-28s %.4f ms frac %.4f\n", lg, w, NAME, ms, n * BYTES / ms / 1e6 / 8000.0);
-                SRUN("tri stride 16 / 3", (k_tri_stride<8192, 16, 3>), 76.0)
-                SRUN("tri stride 17 / 3", (k_tri_stride<8192, 17, 3>), 76.0)
-                SRUN("tri stride 18 / 3", (k_tri_stride<8192, 18, 3>), 76.0)
-                SRUN("tri stride 20 / 3", (k_tri_stride<8192, 20, 3>), 76.0)
-                SRUN("tri stride 16 / 4", (k_tri_stride<8192, 16, 4>), 76.0)
-                SRUN("tri stride 17 / 4", (k_tri_stride<8192, 17, 4>), 76.0)
-                SRUN("tri stride 19 / 5", (k_tri_stride<8192, 19, 5>), 76.0)
-                SRUN("box stride 34 / 5", (k_box_stride<8192, 34, 5>), 156.0)
-                SRUN("box stride 35 / 5", (k_box_stride<8192, 35, 5>), 156.0)
-                SRUN("box stride 36 / 6", (k_box_stride<8192, 36, 6>), 156.0)
-                SRUN("box stride 32+8 / 8", (k_box_stride<8192, 40, 8>), 156.0)
-                CK(hipFree(in2)); CK(hipFree(out2));
+                double ms2;
+#define BRUN(NAME, K) ms2 = time_ms([&] { hipLaunchKernelGGL(K, dim3(blocks), dim3(256), lds_for(w) > 5120 ? lds_for(w) - 5120 : 0, 0, in, out, n); }, 10, 40); \
+                printf("box n 2^%d cap %2d  %-28s %.4f ms frac %.4f\n", lg, w, NAME, ms2, n * 156.0 / ms2 / 1e6 / 8000.0);
+                ms2 = time_ms([&] { hipLaunchKernelGGL((k_tiled_vp<8192, 6>), dim3(blocks), dim3(256), lds_for(w), 0, in, out, n); }, 10, 40);
+                printf("box n 2^%d cap %2d  %-28s %.4f ms frac %.4f\n", lg, w, "4-byte stores", ms2, n * 156.0 / ms2 / 1e6 / 8000.0);
+                BRUN("16-byte stores through LDS", (k_tiled_wide_st<8192>))
             }
             fflush(stdout);
         }
