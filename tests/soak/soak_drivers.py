@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Parity soak of the drivers above the op kernels, with randomly drawn shapes: record streams (both modes, whole
+"""Parity soak of the drivers above the op kernels, with randomly drawn shapes: record streams (all three modes, whole
 and in random pieces), the k-NN searches (exhaustive, tree walk, leaf-major; Euclidean and angular), the
 closest-hit traversal (both walks) and the hit-mask compaction, each against the CPU oracle or a model built from
 it.  Not part of the test suite (minutes of run time):
@@ -44,7 +44,7 @@ def soak_stream(rng, seed):
     want, state = O.eval_bundles("B", stream.view(O.IN_BUNDLE).reshape(-1), extended=True)
     want = want.view(u32).reshape(-1, 21)
     ok = True
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         c = capi.Context()
         c.set_option("stream_mode", mode)
         n = stream.shape[0]
@@ -56,6 +56,10 @@ def soak_stream(rng, seed):
             c.eval_bundles_device(d_in, d_out)
             got.append(d_out.cpu().numpy().view(u32))
         ok &= same(np.concatenate(got), want) and tuple(int(x) for x in c.get_accum().view(u32)) == state
+        ok &= c.get_option("stream_giveups") == 0
+        # the host entry point (pinned single-synchronisation path for small streams) from the same registers
+        c.reset()
+        ok &= same(c.eval_bundles(stream), want) and tuple(int(x) for x in c.get_accum().view(u32)) == state
         c.close()
     return ok, "stream %s" % (sizes,)
 
