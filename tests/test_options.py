@@ -152,8 +152,11 @@ def test_a_batch_captured_into_a_graph_replays_with_new_operands_and_carries_the
     flags = torch.empty(n_box, dtype=torch.int32, device="cuda")
     acc = torch.empty(n_beats, dtype=torch.float32, device="cuda")
     dot, norm = torch.empty(n_beats, dtype=torch.float32, device="cuda"), torch.empty(n_beats, dtype=torch.float32, device="cuda")
+    # the box segment in tiled form (one operand and one result buffer), the beats as plain arrays
+    box_in = torch.empty(capi.tiled_words(n_box, 34), dtype=torch.float32, device="cuda")
+    box_out = torch.empty(capi.tiled_words(n_box, 5), dtype=torch.int32, device="cuda")
     bt = capi.Batch()
-    bt.set_box(d_fields, tmin, flags)
+    bt.set_box_tiled(box_in, box_out, n_box)
     bt.set_euclid(d_a, d_b, d_ctl, acc)
     bt.set_angular(d_qa, d_qb, d_qctl, dot, norm)
     bt.finalize()
@@ -165,11 +168,15 @@ def test_a_batch_captured_into_a_graph_replays_with_new_operands_and_carries_the
         d_a.copy_(dev(a)); d_b.copy_(dev(b)); d_ctl.copy_(dev(ctl.view(np.int32)))
         d_qa.copy_(dev(qa)); d_qb.copy_(dev(qb)); d_qctl.copy_(dev(qctl.view(np.int32)))
         torch.cuda.synchronize()
+        ctx.tile_pack(d_fields, box_in, n_box)
+        ctx.synchronize()
 
     state = [f32(0), f32(0), f32(0)]
 
     def check(r, what):
         fields, a, b, ctl, qa, qb, qctl = rounds[r]
+        ctx.tile_unpack(box_out, [t.view(torch.int32) for t in tmin] + [flags], n_box)
+        ctx.synchronize()
         want_t, want_f = oracle.box_soa(fields)
         want_acc, state[0] = oracle.euclid_beats(a, b, ctl, state[0])
         want_dot, want_norm, state[1], state[2] = oracle.angular_beats(qa, qb, qctl, state[1], state[2])
@@ -182,6 +189,7 @@ def test_a_batch_captured_into_a_graph_replays_with_new_operands_and_carries_the
 
     stream = torch.cuda.Stream()
     ctx.reset()
+    load(0)
     ctx.launch(bt, stream.cuda_stream)           # direct, also the kernels' one-time set-up
     stream.synchronize()
     check(0, "direct launch before the capture")
