@@ -17,6 +17,26 @@ def even_cuts(n, world):
     return [(n * r) // world for r in range(world + 1)]
 
 
+def tile_cuts(n, world, tile_ops=8192):
+    """world+1 cut points of [0, n) that fall on whole tiles of a tiled segment.
+
+    A tiled segment stores tile t of every word contiguously, so a range that
+    starts and stops on a tile boundary is one contiguous slice of the buffer:
+    words [start * W, stop * W) for W words per op (the last range also takes
+    the partial tile).  Ranges differ by at most one tile.
+    """
+    tiles = -(-int(n) // tile_ops)
+    return [min(int(n), ((tiles * r) // world) * tile_ops) for r in range(world)] + [int(n)]
+
+
+def tiled_slice(buf, words_per_op, start, stop, tile_ops=8192):
+    """The words of ops [start, stop) of a tiled buffer; start must be tile-aligned."""
+    if start % tile_ops:
+        raise ValueError("a tiled segment can only be cut on a tile boundary")
+    end_tiles = -(-int(stop) // tile_ops)
+    return buf[start * words_per_op: end_tiles * tile_ops * words_per_op]
+
+
 def snap_to_pair_boundary(ctl, pos):
     """Smallest boundary >= pos: an index i with i == 0, i == n or reset(ctl[i-1])."""
     n = int(ctl.shape[0])

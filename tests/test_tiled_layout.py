@@ -74,3 +74,30 @@ def test_the_layout_is_a_bijection_onto_whole_tiles():
         assert np.unique(idx).size == n * words
         first = tile_index(np.arange(min(n, T)), 2 % words, words)
         assert (np.diff(first) == 1).all()
+
+
+def test_tile_aligned_shards_are_contiguous_slices_of_the_buffer():
+    """shard.tile_cuts cuts a tiled segment on tile boundaries, so each rank's ops are one slice of the buffer and the slices
+    re-tile to exactly what packing the rank's own ops would give."""
+    from raytracer_amd import shard
+    words = 5
+    for n in (0, 1, T - 1, T, 5 * T + 77, 16 * T):
+        plain = np.arange(n * words, dtype=np.uint32).reshape(words, n)          # word k of op i
+        buf = np.zeros(capi.tiled_words(n, words), dtype=np.uint32)
+        i = np.arange(n)
+        for k in range(words):
+            buf[tile_index(i, k, words)] = plain[k]
+        for world in (1, 2, 3, 8):
+            cuts = shard.tile_cuts(n, world)
+            assert cuts[0] == 0 and cuts[-1] == n and all(a <= b for a, b in zip(cuts[:-1], cuts[1:]))
+            assert all(c % T == 0 for c in cuts[:-1])
+            sizes = [b - a for a, b in zip(cuts[:-1], cuts[1:])]
+            assert max(sizes) - min(sizes) <= T
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                part = shard.tiled_slice(buf, words, a, b)
+                assert part.shape[0] == capi.tiled_words(b - a, words)
+                j = np.arange(b - a)
+                for k in range(words):
+                    assert (part[tile_index(j, k, words)] == plain[k, a:b]).all()
+    with pytest.raises(ValueError):
+        shard.tiled_slice(np.zeros(4 * T * words, dtype=np.uint32), words, 5, T)
