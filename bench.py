@@ -121,6 +121,7 @@ def parse():
                    help="box / triangle segments as one tiled buffer per segment ([tile][word][8192 ops], RT_DP_F_BOX_TILED / "
                         "RT_DP_F_TRI_TILED: the layout the library recommends) or as one array per operand (plain); the default "
                         "line reports both")
+    p.add_argument("--ballast-gib", type=float, default=0.0, help="diagnostic: hold this much other device memory, allocated before the workload's arrays")
     p.add_argument("--verify", action="store_true", help="sharded mixed stream: also evaluate the whole stream on rank 0 and compare it with the "
                                                          "shards' results put together (small sizes only: results travel through host memory)")
     a = p.parse_args()
@@ -736,6 +737,7 @@ def main():
         which, only_edge = [a.only.split("_")[0]], a.edge_per_class
     if a.derive:
         BYTES.update(box=144, tri=72)
+    ballast = torch.empty(int(a.ballast_gib * 2 ** 30), dtype=torch.uint8, device=dev).fill_(1) if a.ballast_gib > 0 else None  # noqa: F841
     batches = make_batches(n, dev, which, a.stagger_kib, bool(a.derive), a.launch_ops, only_edge, a.layout, ctx)
     torch.cuda.synchronize()
 
