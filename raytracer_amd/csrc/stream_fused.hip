@@ -582,15 +582,18 @@ __global__ void k_stream_chain_state(StreamChain ch, const float *__restrict__ s
     state_out[2] = la ? canon_nan(__uint_as_float((uint32_t)ch.word[2][la - 1u])) : state_in[2];
 }
 
+// Address `off` bytes into a workspace; integer arithmetic, so that a layout can also be laid over a null base to learn its size.
+template <typename T> static T *ws_at(char *base, size_t off) { return reinterpret_cast<T *>(reinterpret_cast<uintptr_t>(base) + off); }
+
 static StreamChain stream_chain_layout(char *workspace, uint64_t capacity, size_t *piece_bytes) {
     const uint64_t waves = (capacity + 63) / 64;
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     StreamChain ch;
     size_t o = 0;
-    ch.sticky = reinterpret_cast<unsigned long long *>(workspace + o); o += 256;
+    ch.sticky = ws_at<unsigned long long>(workspace, o); o += 256;
     const size_t piece0 = o;
-    ch.last = reinterpret_cast<uint32_t *>(workspace + o); o += 256;
-    for (int k = 0; k < 3; ++k) { ch.word[k] = reinterpret_cast<unsigned long long *>(workspace + o); o += up(waves * 8); }
+    ch.last = ws_at<uint32_t>(workspace, o); o += 256;
+    for (int k = 0; k < 3; ++k) { ch.word[k] = ws_at<unsigned long long>(workspace, o); o += up(waves * 8); }
     if (piece_bytes) *piece_bytes = o - piece0;
     return ch;
 }
@@ -631,12 +634,12 @@ static StreamSide stream_fused_layout(char *workspace, uint64_t capacity, size_t
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     StreamSide side;
     size_t o = 0;
-    side.tag = reinterpret_cast<uint32_t *>(workspace + o); o += up(capacity * 4);
-    side.sum0 = reinterpret_cast<float *>(workspace + o); o += up(capacity * 4);
-    side.sum1 = reinterpret_cast<float *>(workspace + o); o += up(capacity * 4);
-    side.rbits[0] = reinterpret_cast<uint32_t *>(workspace + o); o += up(nwords * 4);
-    side.rbits[1] = reinterpret_cast<uint32_t *>(workspace + o); o += up(nwords * 4);
-    side.flags = reinterpret_cast<uint32_t *>(workspace + o);
+    side.tag = ws_at<uint32_t>(workspace, o); o += up(capacity * 4);
+    side.sum0 = ws_at<float>(workspace, o); o += up(capacity * 4);
+    side.sum1 = ws_at<float>(workspace, o); o += up(capacity * 4);
+    side.rbits[0] = ws_at<uint32_t>(workspace, o); o += up(nwords * 4);
+    side.rbits[1] = ws_at<uint32_t>(workspace, o); o += up(nwords * 4);
+    side.flags = ws_at<uint32_t>(workspace, o);
     if (bits_bytes) *bits_bytes = 2 * up(nwords * 4);
     return side;
 }
@@ -644,7 +647,7 @@ static StreamSide stream_fused_layout(char *workspace, uint64_t capacity, size_t
 size_t stream_fused_workspace(uint64_t capacity) {
     size_t bits = 0;
     const StreamSide side = stream_fused_layout(nullptr, capacity, &bits);
-    return static_cast<size_t>(reinterpret_cast<char *>(side.flags) - static_cast<char *>(nullptr)) + 256;
+    return static_cast<size_t>(reinterpret_cast<uintptr_t>(side.flags)) + 256;
 }
 
 // One piece of n <= capacity records.  first_piece: also clears the sticky "opcode > 3" word, once per call.
