@@ -816,12 +816,21 @@ def main():
         del batches, batch
         torch.cuda.empty_cache()
         # config 4: the 2^28-unit mixed stream, one shard per GPU
-        extras["mixed_2p%d" % a.strong_log2_ops] = strong_mixed_measure(a, ctx, world, rank, dev, dist, a.strong_log2_ops, a.steps, a.warmup)
-        extras["mixed_2p%d_%s" % (a.strong_log2_ops, other)] = strong_mixed_measure(a, ctx, world, rank, dev, dist, a.strong_log2_ops, a.steps, a.warmup, other)
+        def guarded(fn, *args):
+            # an entry that fails (the same way on every rank: a shape or argument error) is reported as such instead of
+            # taking the headline measured above down with it
+            try:
+                return fn(*args)
+            except Exception as e:  # noqa: BLE001
+                torch.cuda.empty_cache()
+                return {"error": "%s: %s" % (type(e).__name__, e)}
+
+        extras["mixed_2p%d" % a.strong_log2_ops] = guarded(strong_mixed_measure, a, ctx, world, rank, dev, dist, a.strong_log2_ops, a.steps, a.warmup)
+        extras["mixed_2p%d_%s" % (a.strong_log2_ops, other)] = guarded(strong_mixed_measure, a, ctx, world, rank, dev, dist, a.strong_log2_ops, a.steps, a.warmup, other)
         # config 5: k-NN, exhaustive and leaf-major
         ksteps, kwarm = max(1, min(a.steps, 5)), max(1, min(a.warmup, 2))
-        extras["knn"] = {"exhaustive": knn_measure(a, ctx, world, rank, dev, 0, ksteps, kwarm),
-                         "leaf_major": knn_measure(a, ctx, world, rank, dev, 2, ksteps, kwarm)}
+        extras["knn"] = {"exhaustive": guarded(knn_measure, a, ctx, world, rank, dev, 0, ksteps, kwarm),
+                         "leaf_major": guarded(knn_measure, a, ctx, world, rank, dev, 2, ksteps, kwarm)}
 
     head = which[0]
     r = results[head]
