@@ -118,6 +118,32 @@ def test_tiled_triangle_ops_match_the_oracle(ctx, oracle, torch_cuda, n):
     assert_bits_equal(gh, wh, "hit")
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_tile_aligned_shards_of_a_tiled_segment(ctx, oracle, torch_cuda, world):
+    """shard.tile_cuts: every rank's part of a tiled segment is a slice of the buffer (no re-packing) and a valid tiled segment of
+    its own; the parts' results, put together in rank order, are the oracle's results for the whole segment."""
+    from raytracer_amd import shard
+    torch = torch_cuda
+    n = 5 * T + 77
+    fields = [np.ascontiguousarray(f) for f in gen.box_ops(n, seed=4711, edge_frac=0.2)]
+    want_t, want_f = oracle.box_soa(fields)
+    operands = torch.from_numpy(pack_numpy(fields).view(np.int32)).cuda()
+    results = torch.full((capi.tiled_words(n, 5),), SENTINEL, dtype=torch.int32, device="cuda")
+    cuts = shard.tile_cuts(n, world)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b == a:
+            continue
+        batch = capi.Batch()
+        batch.set_box_tiled(shard.tiled_slice(operands, 34, a, b), shard.tiled_slice(results, 5, a, b), b - a)
+        torch.cuda.synchronize()
+        ctx.eval(batch)
+    raw = results.cpu().numpy().view(u32)
+    out = unpack_numpy(raw, 5, n)
+    for k in range(4):
+        assert_bits_equal(out[k].view(f32), want_t[k], "tmin_out[%d]" % k)
+    assert_bits_equal(out[4], want_f, "flags")
+
+
 @pytest.mark.parametrize("n", [1, 257, T + 1, 50021])
 def test_tiled_segments_with_derived_ray_fields(ctx, torch_cuda, n):
     """RT_DP_F_DERIVE_RAY over tiled segments: the bits of the plain derive path (which the derive tests pin against
