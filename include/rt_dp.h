@@ -571,7 +571,7 @@ int rt_dp_set_tuning(rt_dp_ctx *ctx, int ops_per_lane, int nontemporal, int vec_
  * pattern without its arithmetic, outputs meaningless; the beat kernels have two shapes with identical results -- "owning": a workgroup owns whole vector
  * pairs and searches for their boundaries; "chained": fixed tiles that hand their running sums on from one to the
  * next through a workspace inside the context -- and each opcode defaults to the one that measured faster (Euclidean
- * chained, angular owning); 23: owning for both (21 / 22: with one or the other form of its serial accumulation),
+ * chained; angular owning, chained for segments of up to 2^23 beats); 23: owning for both (21 / 22: with one or the other form of its serial accumulation),
  * 27: chained for both, 24 / 25 diagnostic: chained without the accumulation / without the LDS stage either,
  * outputs meaningless).  "vec_tile" applies to the owning shape only.  Environment: RT_DP_VEC_PASSES,
  * RT_DP_VARIANT.  "wgs_per_cu" (resident 256-thread workgroups per CU of the box / triangle / beat

@@ -1121,7 +1121,12 @@ template <bool EUC> static hipError_t launch_vec(const VecArgs &args, uint64_t n
     // process (scripts/bench_ctx.sh, 2^24 beats): Euclidean 0.814 chained against 0.800 owning, angular 0.745 chained
     // against 0.762 owning, so each opcode defaults to its better shape.  Variant 23 (21, 22): owning for both; 27
     // (24, 25): chained for both.
-    const bool chained = args.chain != nullptr && (t.variant == 27 || t.variant == 24 || t.variant == 25 || (EUC && !(t.variant >= 21 && t.variant <= 23)));
+    // Short angular segments (the quarters of a mixed batch, the segments behind the opcode partition of a record stream) are
+    // the exception: up to 2^23 beats the chained shape leads on every box measured (2^22 beats: 0.66 against 0.64 of the HBM
+    // peak, 2^20: 0.52 against 0.49; scripts/beat_shapes.sh, scripts/ang_shape_check.sh), above that the two trade places by
+    // less than the box-to-box spread.
+    const bool short_angular = !EUC && n <= (1ull << 23);
+    const bool chained = args.chain != nullptr && (t.variant == 27 || t.variant == 24 || t.variant == 25 || ((EUC || short_angular) && !(t.variant >= 21 && t.variant <= 23)));
     if (chained) {
         VecArgs a2 = args;
         a2.diag = (t.variant == 24) ? 1u : (t.variant == 25) ? 2u : 0u;
