@@ -18,7 +18,7 @@ for n in (100, 1000, 10000, 50000, 100000):
     s = _mixed_stream(1, n // 4, n // 4, n // 40 + 1, n // 40 + 1)
     print("eval_bundles host, %6d records: %8.1f us" % (s.shape[0], timeit(lambda: c.eval_bundles(s))))
     d_in = torch.from_numpy(s.view(np.int32)).cuda(); d_out = torch.empty((s.shape[0], 21), dtype=torch.int32, device="cuda")
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         c.set_option("stream_mode", mode)
         print("eval_bundles_device mode %d, %6d records: %8.1f us" % (mode, s.shape[0], timeit(lambda: c.eval_bundles_device(d_in, d_out))))
     c.set_option("stream_mode", 0)
