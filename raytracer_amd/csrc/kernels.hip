@@ -1130,7 +1130,10 @@ template <bool EUC> static hipError_t launch_vec(const VecArgs &args, uint64_t n
     if (chained) {
         VecArgs a2 = args;
         a2.diag = (t.variant == 24) ? 1u : (t.variant == 25) ? 2u : 0u;
-        const int passes = (t.vec_passes == 2 || t.vec_passes == 4 || t.vec_passes == 8) ? t.vec_passes : (EUC ? 8 : 4);
+        // Euclidean: eight load pairs per lane on long segments; on short ones twice as many, half as long workgroups fill the
+        // chip better (scripts/euclid_passes.sh, 4 against 8: 2^18 beats 0.44 / 0.40 of the HBM peak, 2^20 0.66 / 0.62, 2^22 equal,
+        // 2^24 0.81 / 0.83)
+        const int passes = (t.vec_passes == 2 || t.vec_passes == 4 || t.vec_passes == 8) ? t.vec_passes : (EUC ? (n <= (1ull << 21) ? 4 : 8) : 4);
         if ((n + 127) / 128 > 0x7FFFFFFFull) return hipErrorInvalidValue;
         // residency: the Euclidean shape (64 KiB of loads in flight per workgroup) is best with 4 workgroups per CU (0.824
         // of the HBM roof against 0.79 with the 6 its registers allow), the angular shape with all it can get
