@@ -307,7 +307,7 @@ def run(ctx, batch, steps, warmup, dist):
         torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1) / steps
-    wall = dist_util.max_over_ranks(wall, device="cuda")
+    wall = dist_util.max_over_ranks(wall)
     return wall, dev_ms
 
 
@@ -401,7 +401,7 @@ def run_stream(a, world, rank, local, dev):
         ctx.eval_bundles_device(rec, out)
     torch.cuda.synchronize()
     dist_util.barrier()
-    wall = dist_util.max_over_ranks(time.perf_counter() - t0, device="cuda")
+    wall = dist_util.max_over_ranks(time.perf_counter() - t0)
     if rank == 0:
         per = wall / a.steps
         print(json.dumps({"metric": "datapath records/s (AoS record stream, mixed opcodes)", "value": round(n * world / per, 1), "unit": "records/s",
@@ -454,7 +454,7 @@ def run_trace(a, world, rank, local, dev):
         stats = ctx.trace_closest(N, T, o, d, 4000.0, out_t, out_i, wavefront=bool(a.trace_wavefront))
     torch.cuda.synchronize()
     dist_util.barrier()
-    wall = dist_util.max_over_ranks(time.perf_counter() - t0, device="cuda")
+    wall = dist_util.max_over_ranks(time.perf_counter() - t0)
     if rank == 0:
         per = wall / a.steps
         hits = float((out_i != -1).float().mean().item())
@@ -491,6 +491,7 @@ def knn_measure(a, ctx, world, rank, dev, tree_mode, steps, warmup):
     angular = a.knn_metric == "angular"
     if angular:
         tree_mode = 0
+    group = dist_util.data_group()   # RCCL if it works on every rank, else None: the exchange is staged through the host over gloo
     if tree_mode:
         from raytracer_amd import knn_tree
         torch.cuda.synchronize()
@@ -510,16 +511,16 @@ def knn_measure(a, ctx, world, rank, dev, tree_mode, steps, warmup):
             dist_util.barrier()
             t0 = time.perf_counter()
             if tree is not None:
-                d, i = knn_tree.search(ctx, tree, qry, splits=a.knn_splits or None, grouped=(tree_mode == 2), walk_leaves=a.knn_walk)
+                d, i = knn_tree.search(ctx, tree, qry, group=group, splits=a.knn_splits or None, grouped=(tree_mode == 2), walk_leaves=a.knn_walk)
             elif angular:
-                d, i = knn.unpack_signed_keys(knn.all_gather_merge(knn.local_topk_angular(ctx, shard_pts, qry, lo, splits=a.knn_splits or None)))
+                d, i = knn.unpack_signed_keys(knn.all_gather_merge(knn.local_topk_angular(ctx, shard_pts, qry, lo, splits=a.knn_splits or None), group=group))
             else:
-                d, i = knn.search(ctx, shard_pts, qry, lo, splits=a.knn_splits or None)
+                d, i = knn.search(ctx, shard_pts, qry, lo, group=group, splits=a.knn_splits or None)
             torch.cuda.synchronize()
             dist_util.barrier()
             if it >= warmup:
                 times.append(time.perf_counter() - t0)
-    wall = dist_util.max_over_ranks(sum(times), device="cuda")
+    wall = dist_util.max_over_ranks(sum(times))
     per = wall / steps
     pairs = float(n_pts) * n_qry
     if angular:   # the candidate's norm is computed once per point, not per pair
@@ -532,7 +533,7 @@ def knn_measure(a, ctx, world, rank, dev, tree_mode, steps, warmup):
             "workload": "knn: 2^%d points sharded over %d GPU(s), 2^%d queries replicated, dim 16, k 16, %s data, one all-gather merge" % (
                 a.knn_log2_points, world, a.knn_log2_queries, a.knn_data),
             "search": ("k-d tree %s, leaf %d, index build %.1f ms (not timed)" % ("leaf-major search" if tree_mode == 2 else "walk with box pruning", a.knn_leaf, build_ms)) if tree_mode else "exhaustive",
-            "pair_rate_equivalent_per_s": round(pairs / per, 1),
+            "pair_rate_equivalent_per_s": round(pairs / per, 1), "exchange": dist_util.data_backend(),
             "valu": None if tree_mode else {"lane_ops_per_pair": lane_ops, "achieved_T_lane_ops": round(pairs * lane_ops / per / 1e12, 2), "peak_T_lane_ops": 78.6,
                                             "frac": round(pairs * lane_ops / per / 78.6e12, 4), "note": note}}
 
@@ -690,14 +691,14 @@ def main():
     if a.gpus != world and rank == 0:
         print("bench.py: --gpus %d but the launch environment has %d rank(s); reporting n_gpus = %d" % (a.gpus, world, world), file=sys.stderr)
     if os.environ.get("RT_DP_REHEARSE_ONE_GPU") == "1":
-        # rehearsal of the N > 1 control path on a one-GPU box: every rank uses GPU 0 and the
-        # control collectives go over gloo (RCCL refuses two ranks on one device); timings are meaningless
+        # rehearsal of the N > 1 path on a one-GPU box: every rank uses GPU 0 (RCCL refuses two ranks on one
+        # device, so the k-NN exchange is staged through the host as well); timings are meaningless
         local = 0
-        torch.cuda.set_device(0)
-        dist_util.init("gloo")
-    else:
-        torch.cuda.set_device(local)
-        dist_util.init("nccl")  # RCCL; a no-op for a single process
+    torch.cuda.set_device(local)
+    # Control (barriers, max of the wall times, small objects) always goes over gloo with host tensors, so the sharded
+    # op streams, which have no collective, report their numbers whether or not RCCL comes up; RCCL is used for the
+    # k-NN all-gather only (dist_util.data_group, created and verified on first use, host staging if it fails).
+    dist_util.init("gloo")
     dist = torch.distributed if world > 1 else None
     dev = torch.device("cuda", local)
     n = a.ops if a.ops else 1 << a.log2_ops

@@ -227,8 +227,9 @@ int rt_dp_eval_ctx(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch 
  * synchronising.  Ordering against the producers of the operands is the
  * caller's: launch on the stream that produced them, or synchronise first.
  * Batches of one context execute in the order they were given (they share its
- * accumulator registers and its workspace): a caller that launches batches of ONE
- * context on different streams must order those streams itself.
+ * accumulator registers and its workspace): the library orders a batch with beats behind
+ * the beat batches it put on other streams before (events both ways; not under graph
+ * capture); box / triangle batches carry no state and are not ordered.
  * The same holds for every entry point below that is described as
  * asynchronous (rt_dp_ray_prepare, rt_dp_knn_euclid16, rt_dp_knn_angular16,
  * rt_dp_knn_tree_euclid16); the synchronous ones wait for the whole device
@@ -238,7 +239,20 @@ int rt_dp_eval_ctx(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch 
  * allocated, and every replay evaluates whatever the same arrays hold by then.
  * The accumulator registers carry from replay to replay and to and from batches
  * launched directly, in the order the work executes; run one such batch directly
- * before capturing, so that the one-time set-up of the kernels is not captured. */
+ * before capturing, so that the one-time set-up of the kernels is not captured.
+ *
+ * Failure that only shows after the kernels ran: the default Euclidean kernel (and the angular one on short segments)
+ * hands the running sum of a vector pair that spans two workgroups from one to the next; the receiving workgroup
+ * waits a bounded time (about a second).  Should that wait ever run out (a lost or starved workgroup), the beat
+ * results of that batch are not valid.  The synchronous entry points (rt_dp_eval, rt_dp_eval_ctx, rt_dp_eval_bundles,
+ * rt_dp_eval_bundles_device) notice it with the results they wait for anyway and evaluate the beat segments again
+ * with kernels that need no hand-over: they never return RT_DP_OK with such results.  Behind rt_dp_launch the
+ * library holds no batch to repeat: rt_dp_synchronize and rt_dp_get_accum return RT_DP_EHIP instead, once, for the
+ * batches launched since the last of those calls; a caller of rt_dp_launch must look at one of them before it
+ * trusts beat results (or launch with option "variant" 23, whose kernels have no hand-over).
+ *
+ * rt_dp_synchronize waits for every batch the context was given, on its own stream and (through the event
+ * the library records behind them) on caller streams; a batch captured into a graph is the caller's to wait for. */
 int rt_dp_launch(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *out, void *hip_stream);
 int rt_dp_synchronize(rt_dp_ctx *ctx);
 
@@ -309,6 +323,34 @@ int rt_dp_eval_bundles(rt_dp_ctx *ctx, const rt_dp_input_bundle *in, rt_dp_outpu
  * stream order), the evaluation and the re-assembly of the output records all run on
  * the GPU; only the four per-opcode counts travel to the host.  Synchronous.           */
 int rt_dp_eval_bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt_dp_output_bundle *d_out, uint64_t n);
+
+/* ---- one stream over several contexts / GPUs -----------------------------------------------
+ * The RTL is one datapath fed by one producer and drained by one consumer thread
+ * (src/test/scala/raytracer_datapath/Datapath_test.scala:476-496).  Here a stream may be cut into
+ * parts that are evaluated independently, one host thread + one context (+ its stream) per GPU, with no
+ * communication between them: box and triangle ops carry no state, and a distance beat carries the
+ * accumulator registers on only when its reset bit is clear (UnifiedDatapath.scala:1133-1154, :1028-1064),
+ * so every cut is placed where the registers hold +0 -- which is what a fresh (or reset) context starts
+ * from.  The parts' results, put together in order, are then bit for bit those of the whole stream on one
+ * context that started from reset registers.  Host arrays, no GPU involved; the planners are pure functions.
+ *
+ * rt_dp_shard_plan: an opcode-sorted batch with n[opcode] units per segment; euc_ctl / ang_ctl are the
+ *   segments' control words (host memory; may be NULL for an empty segment).  out[r] receives part r's range
+ *   [start, stop) of every segment: contiguous near-equal ranges, the cuts of the beat segments moved forward
+ *   to the next vector-pair boundary (a part can be empty when one pair spans several nominal ranges).
+ *   flags: RT_DP_F_BOX_TILED / RT_DP_F_TRI_TILED place that segment's cuts on multiples of RT_DP_TILE_OPS, so
+ *   that a part of a tiled segment is itself a tiled segment: the words from start * W on (W words per op).
+ * rt_dp_shard_plan_records: a record stream in arrival order (any opcode mix); cuts[0..world] receives
+ *   ascending record positions, cuts[0] = 0, cuts[world] = n; cut r is the first position at or after
+ *   n * r / world in front of which neither distance opcode has a vector pair under way.                   */
+typedef struct rt_dp_shard_range {
+    uint64_t start[4]; /* indexed by rt_dp_opcode */
+    uint64_t stop[4];
+} rt_dp_shard_range;
+
+int rt_dp_shard_plan(const uint64_t n[4], const uint32_t *euc_ctl, const uint32_t *ang_ctl, uint32_t world, uint32_t flags,
+                     rt_dp_shard_range *out /* [world] */);
+int rt_dp_shard_plan_records(const rt_dp_input_bundle *records, uint64_t n, uint32_t world, uint64_t *cuts /* [world + 1] */);
 
 /* ---- vector pairs <-> beats (the format step on either side of the distance ops) ---------
  * The reference's job splitters (src/test/scala/raytracer_datapath/raytracer_gold/SW_Data.scala:
@@ -589,10 +631,12 @@ int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value);
  * dynamic LDS a launch asks for; the amount is verified against that query once per process, so a runtime
  * that hands out LDS differently shows up here instead of silently changing the residency.              */
 int rt_dp_get_option(rt_dp_ctx *ctx, const char *key, int *value);
-/* "stream_giveups" (read only): the same count for the hand-overs from wave to wave of stream_mode 3.
- * "vec_chain_giveups" (read only): hand-overs between tiles of the beat kernels that were given up on after a
- * bounded wait since the context's workspace was last (re)allocated; anything but 0 means the device lost a
- * workgroup and the beat results of that launch are not to be trusted.                                        */
+/* "vec_chain_giveups" (read only): hand-overs between workgroups of the beat kernels that were given up on after a
+ * bounded wait, since the context was created.  "stream_giveups" (read only): the same count for the hand-overs
+ * from wave to wave of stream_mode 3.  "chain_fallbacks" (read only): batches / record streams that a synchronous
+ * entry point evaluated a second time, without hand-overs, because of such a give-up.  All three stay 0 on a
+ * healthy device.  "debug_chain_skip" (write only, for tests): workgroup k of the chained beat kernels does not
+ * publish its running sums and waits are cut to 2^12 polls, so the give-up path can be exercised; -1 turns it off. */
 
 const char *rt_dp_last_error(void);
 const char *rt_dp_version(void);

@@ -20,7 +20,7 @@ ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
           "-fno-gpu-flush-denormals-to-zero", "-Wall", "-Wno-unused-function",
           "-I", os.path.join(ROOT, "include"), "-I", CSRC]
-SOURCES = ["kernels.hip", "knn.hip", "stream.hip", "stream_fused.hip", "trace.hip", "compact.hip", "pairs.hip", "build_device.hip", "build_kd.hip", "api.cpp", "build_index.cpp"]
+SOURCES = ["kernels.hip", "knn.hip", "stream.hip", "stream_fused.hip", "trace.hip", "compact.hip", "pairs.hip", "build_device.hip", "build_kd.hip", "api.cpp", "build_index.cpp", "shard.cpp"]
 HOST_TOOLS = {"rt_dp_replay": ["rt_dp_replay.cpp"]}
 
 
@@ -38,15 +38,32 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def _compile(job):
+    cmd, verbose = job
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
 def build(force=False, verbose=False):
+    """One object per source (compiled in parallel, only when the source or a header is newer), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "rt_dp.h"), __file__]
-    if force or _stale(LIB, deps):
-        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-x", "hip"] + COMMON + ["-shared", "-o", LIB] + \
-              [os.path.join(CSRC, s) for s in SOURCES]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))] + [os.path.join(ROOT, "include", "rt_dp.h"), __file__]
+    jobs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [os.path.join(CSRC, src)] + headers):
+            jobs.append(([_hipcc(), "--offload-arch=" + ARCH, "-x", "hip"] + COMMON + ["-c", os.path.join(CSRC, src), "-o", obj], verbose))
+    if jobs:
+        workers = max(1, min(len(jobs), int(os.environ.get("MAX_JOBS", "0")) or (os.cpu_count() or 4), 8))
+        with ThreadPoolExecutor(workers) as pool:
+            list(pool.map(_compile, jobs))
+    if force or jobs or _stale(LIB, objs):
+        _compile(([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs, verbose))
     for tool, srcs in HOST_TOOLS.items():
         paths = [os.path.join(CSRC, s) for s in srcs]
         if not all(os.path.exists(p) for p in paths):
@@ -54,17 +71,18 @@ def build(force=False, verbose=False):
         out = os.path.join(LIBDIR, tool)
         if force or _stale(out, paths + [LIB]):
             cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", out] + paths + \
-                  ["-L", LIBDIR, "-lrt_dp", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+                  ["-L", LIBDIR, "-lrt_dp", "-pthread", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
-    ex_src, ex = os.path.join(ROOT, "examples", "kat_from_c.c"), os.path.join(LIBDIR, "kat_from_c")
-    if os.path.exists(ex_src) and (force or _stale(ex, [ex_src, LIB, os.path.join(ROOT, "include", "rt_dp.h")])):
-        cmd = ["gcc", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), ex_src, "-o", ex, "-L", LIBDIR, "-lrt_dp", "-lm",
-               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]  # plain C: the header and the ABI without any C++
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+    for name in ("kat_from_c", "multi_gpu"):   # plain C: the header and the ABI without any C++
+        ex_src, ex = os.path.join(ROOT, "examples", name + ".c"), os.path.join(LIBDIR, name)
+        if os.path.exists(ex_src) and (force or _stale(ex, [ex_src, LIB, os.path.join(ROOT, "include", "rt_dp.h")])):
+            cmd = ["gcc", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), ex_src, "-o", ex, "-L", LIBDIR, "-lrt_dp", "-lm", "-pthread",
+                   "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
     mb_src, mb = os.path.join(CSRC, "membench.hip"), os.path.join(LIBDIR, "membench")
     if os.path.exists(mb_src) and (force or _stale(mb, [mb_src])):
         cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", mb_src, "-o", mb]

@@ -135,7 +135,12 @@ class KnnTree(C.Structure):
 EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize", "rt_dp_tile_pack", "rt_dp_tile_unpack",
            "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_get_option", "rt_dp_knn_euclid16", "rt_dp_knn_angular16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_box_compact", "rt_dp_box_compact_tiled", "rt_dp_box_compact_static", "rt_dp_beat_offsets_host", "rt_dp_pairs_to_beats", "rt_dp_beats_to_pairs", "rt_dp_bvh4_build_device", "rt_dp_knn_tree_build_device", "rt_dp_knn_home_leaf", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
            "rt_dp_knn_tree_leaves", "rt_dp_knn_tree_build_host", "rt_dp_knn_home_leaf_host", "rt_dp_bvh4_max_nodes", "rt_dp_bvh4_build_host",
+           "rt_dp_shard_plan", "rt_dp_shard_plan_records",
            "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
+
+
+class ShardRange(C.Structure):
+    _fields_ = [("start", C.c_uint64 * 4), ("stop", C.c_uint64 * 4)]
 
 
 class RtDpError(RuntimeError):
@@ -196,6 +201,8 @@ def load():
     L.rt_dp_knn_home_leaf_host.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.rt_dp_bvh4_max_nodes.argtypes = [C.c_uint32]
     L.rt_dp_bvh4_build_host.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
+    L.rt_dp_shard_plan.argtypes = [C.POINTER(C.c_uint64 * 4), vp, vp, C.c_uint32, C.c_uint32, C.POINTER(ShardRange)]
+    L.rt_dp_shard_plan_records.argtypes = [vp, C.c_uint64, C.c_uint32, vp]
     L.rt_dp_last_error.restype = C.c_char_p
     L.rt_dp_version.restype = C.c_char_p
     for name in EXPORTS:
@@ -645,6 +652,29 @@ def version():
 
 def device_count():
     return load().rt_dp_device_count()
+
+
+def shard_plan(n_tri, n_box, euc_ctl, ang_ctl, world, box_tiled=False, tri_tiled=False):
+    """rt_dp_shard_plan on host arrays (numpy uint32 control words, or None for an empty segment).  Returns, per part,
+    {"tri": (start, stop), "box": ..., "euclid": ..., "angular": ...} like raytracer_amd.shard.plan."""
+    L = load()
+    e = None if euc_ctl is None else np.ascontiguousarray(euc_ctl).view(np.uint32)
+    a = None if ang_ctl is None else np.ascontiguousarray(ang_ctl).view(np.uint32)
+    n = (C.c_uint64 * 4)(int(n_tri), int(n_box), 0 if e is None else e.shape[0], 0 if a is None else a.shape[0])
+    out = (ShardRange * int(world))()
+    flags = (F_BOX_TILED if box_tiled else 0) | (F_TRI_TILED if tri_tiled else 0)
+    _check(L.rt_dp_shard_plan(C.byref(n), None if e is None else e.ctypes.data, None if a is None else a.ctypes.data, int(world), flags, out))
+    names = ("tri", "box", "euclid", "angular")
+    return [{names[op]: (int(r.start[op]), int(r.stop[op])) for op in range(4)} for r in out]
+
+
+def shard_plan_records(records, world):
+    """rt_dp_shard_plan_records on a host record stream ([n, 84] uint32 words).  Returns the world + 1 cut positions."""
+    L = load()
+    raw = np.ascontiguousarray(records).view(np.uint32).reshape(-1, 84)
+    cuts = np.zeros(int(world) + 1, np.uint64)
+    _check(L.rt_dp_shard_plan_records(raw.ctypes.data, raw.shape[0], int(world), cuts.ctypes.data))
+    return [int(c) for c in cuts]
 
 
 def knn_tree_build_host(points, leaf_size=128, index_base=0):

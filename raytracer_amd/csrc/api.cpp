@@ -40,11 +40,22 @@ constexpr uint64_t kMaxOps = 1ull << 40;
 
 }  // namespace
 
+namespace rtdp {
+// for the other host-side sources of the library (shard.cpp): same per-thread message buffer as rt_dp_last_error()
+int api_fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace rtdp
+
 struct rt_dp_ctx {
     int device = 0;
     bool extended = true;  // support_euclidean == Some(16)
     hipStream_t stream = nullptr;
-    unsigned long long *h_words = nullptr;  // 8 pinned host words: small read-backs (flags, counts) land here without a staging copy
+    unsigned long long *h_words = nullptr;  // 16 pinned host words: small read-backs (flags, counts) land here without a staging copy; [15]: the give-up count
     // accumulator registers live in HBM; two copies so that the workgroup that
     // reads the incoming value never races the one that writes the outgoing one
     // The accumulator registers, [3][4] floats: {euclid, dot, norm, pad}; copy 2 is a call's backup.  A beat kernel reads its
@@ -83,6 +94,18 @@ struct rt_dp_ctx {
     size_t chain_bytes = 0;
     uint32_t chain_epoch = 0;
     std::vector<char *> chain_retired;
+    // Word 0 counts hand-overs that a chained beat kernel gave up on (a bounded wait ran out).  It lives apart from the
+    // hand-over words, so the count survives their re-allocation.  Every entry point that waits for its results reads it
+    // with them and, when it moved, evaluates the beat segments again in the shape that needs no hand-over.
+    unsigned long long *d_chain_hdr = nullptr;
+    unsigned long long chain_seen = 0;       // the count when it was last looked at
+    unsigned long long chain_fallbacks = 0;  // batches whose beat segments were evaluated again after a give-up
+    bool chain_dirty = false;                // a chained kernel was launched since the count was last looked at
+    int debug_chain_skip = -1;               // test hook: this workgroup of the chained kernels does not publish (-1: off)
+    // beat batches that rt_dp_launch put on the context's own stream and nobody has waited for yet: a batch on a caller
+    // stream is ordered behind them through this event
+    hipEvent_t own_done = nullptr;
+    bool own_pending = false;
     Tuning tuning{0, 0, 0, 0, 0, 0};
     int stream_mode = 0;  // record streams in HBM: 0 automatic (2 when the arrays allow it), 1 partition by opcode first, 2 evaluate then fold, 3 single pass
     unsigned long long stream_giveups = 0;  // hand-overs of the single-pass record-stream kernel that were given up on (never, unless a wave is lost)
@@ -207,8 +230,8 @@ int join_caller_stream(rt_dp_ctx *ctx, bool host_too) {
 // runtime and costs several microseconds more).
 int pinned_words(rt_dp_ctx *ctx) {
     if (ctx->h_words) return RT_DP_OK;
-    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_words), 8 * sizeof(unsigned long long), hipHostMallocDefault);
-    if (e != hipSuccess) return fail(RT_DP_ENOMEM, "hipHostMalloc(64) failed: %s", hipGetErrorString(e));
+    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_words), 16 * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e != hipSuccess) return fail(RT_DP_ENOMEM, "hipHostMalloc(128) failed: %s", hipGetErrorString(e));
     return RT_DP_OK;
 }
 
@@ -240,7 +263,42 @@ int chain_for(rt_dp_ctx *ctx, uint64_t n, hipStream_t s, VecArgs &a) {
         ctx->chain_epoch = 1;
     }
     a.chain = reinterpret_cast<unsigned long long *>(ctx->d_chain);
+    a.chain_header = ctx->d_chain_hdr;
     a.epoch = ctx->chain_epoch;
+    a.debug_skip = ctx->debug_chain_skip >= 0 ? (uint32_t)ctx->debug_chain_skip + 1u : 0u;
+    ctx->chain_dirty = true;
+    return RT_DP_OK;
+}
+
+// Enqueues, behind what was launched on s, the read-back of the give-up count into the pinned words.
+int chain_probe(rt_dp_ctx *ctx, hipStream_t s) {
+    if (!ctx->chain_dirty) return RT_DP_OK;
+    int rc = pinned_words(ctx);
+    if (rc != RT_DP_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->h_words + 15, ctx->d_chain_hdr, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    return RT_DP_OK;
+}
+
+// After s has been waited for: did a hand-over give up since the count was last looked at?
+bool chain_moved(rt_dp_ctx *ctx) {
+    if (!ctx->chain_dirty) return false;
+    ctx->chain_dirty = false;
+    const unsigned long long now = ctx->h_words[15];
+    if (now == ctx->chain_seen) return false;
+    ctx->chain_seen = now;
+    return true;
+}
+
+// For callers that hold no batch to evaluate again (rt_dp_synchronize, rt_dp_get_accum): s is idle.
+int chain_verdict(rt_dp_ctx *ctx, hipStream_t s) {
+    if (!ctx->chain_dirty) return RT_DP_OK;
+    int rc = chain_probe(ctx, s);
+    if (rc != RT_DP_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    if (chain_moved(ctx))
+        return fail(RT_DP_EHIP, "a beat kernel gave up waiting for the running sums of its predecessor (a workgroup was lost or starved): the Euclidean / angular "
+                                "results and the accumulator registers of the batches launched since the last rt_dp_synchronize are not valid; "
+                                "rt_dp_eval_ctx evaluates such a batch again by itself");
     return RT_DP_OK;
 }
 
@@ -257,6 +315,70 @@ int commit_state(rt_dp_ctx *ctx, int &cur, bool pinned, int slot, int words, hip
     if (!pinned) { cur ^= 1; return RT_DP_OK; }
     HIP_TRY(hipMemcpyAsync(ctx->d_state + 4 * cur + slot, ctx->d_state + 4 * (cur ^ 1) + slot, words * sizeof(float), hipMemcpyDeviceToDevice, s));
     return RT_DP_OK;
+}
+
+// The beat segments of a batch (extended datapath).  owning_only: the kernel shape that needs no hand-over between
+// workgroups, whatever the defaults say.
+int launch_beats(rt_dp_ctx *ctx, const rt_dp_op_batch *in, const rt_dp_result_batch *out, hipStream_t s, bool owning_only) {
+    const uint64_t n_euc = in->n[RT_DP_OP_EUCLIDEAN], n_ang = in->n[RT_DP_OP_ANGULAR];
+    // (16-byte alignment of a / b: check_batch, before anything was enqueued)
+    // A batch that is being captured into a graph runs again later with the arguments of today: the hand-over
+    // words of the chained kernels are told apart by a per-launch number, which a replay would repeat, so the
+    // captured kernels are the ones that own whole pairs and need no workspace; and the registers stay at the
+    // address the graph holds.
+    const bool captured = is_capturing(s);
+    const bool no_chain = captured || owning_only;
+    if (n_euc) {
+        if (captured) ctx->pinned_e = true;
+        VecArgs a{in->euc.a, in->euc.b, in->euc.ctl, out->euc.accumulator, nullptr, ctx->d_state + 4 * ctx->cur_e, ctx->d_state + 4 * (ctx->cur_e ^ 1)};
+        int rc = no_chain ? RT_DP_OK : chain_for(ctx, n_euc, s, a);
+        if (rc != RT_DP_OK) return rc;
+        HIP_TRY(launch_euclid(a, n_euc, ctx->tuning, s));
+        rc = commit_state(ctx, ctx->cur_e, ctx->pinned_e, 0, 1, s);
+        if (rc != RT_DP_OK) return rc;
+    }
+    if (n_ang) {
+        if (captured) ctx->pinned_a = true;
+        VecArgs a{in->ang.a, in->ang.b, in->ang.ctl, out->ang.dot_product, out->ang.norm, ctx->d_state + 4 * ctx->cur_a + 1,
+                  ctx->d_state + 4 * (ctx->cur_a ^ 1) + 1};
+        int rc = no_chain ? RT_DP_OK : chain_for(ctx, n_ang, s, a);
+        if (rc != RT_DP_OK) return rc;
+        HIP_TRY(launch_angular(a, n_ang, ctx->tuning, s));
+        rc = commit_state(ctx, ctx->cur_a, ctx->pinned_a, 1, 2, s);
+        if (rc != RT_DP_OK) return rc;
+    }
+    return RT_DP_OK;
+}
+
+// The registers as they are before a batch, for the entry points that may have to evaluate its beat segments twice.  A
+// beat kernel leaves the copy it read intact, so going back normally means pointing at that copy again; only a register
+// whose place a captured graph has fixed is overwritten by the batch and needs the backup copy (d_state + 8).
+struct RegSnapshot { int cur_e, cur_a; bool backup; };
+
+int regs_snapshot(rt_dp_ctx *ctx, hipStream_t s, RegSnapshot &snap) {
+    snap = {ctx->cur_e, ctx->cur_a, ctx->pinned_e || ctx->pinned_a};
+    if (snap.backup) {
+        HIP_TRY(hipMemcpyAsync(ctx->d_state + 8, ctx->d_state + 4 * ctx->cur_e, sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(ctx->d_state + 9, ctx->d_state + 4 * ctx->cur_a + 1, 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    return RT_DP_OK;
+}
+
+int regs_restore(rt_dp_ctx *ctx, hipStream_t s, const RegSnapshot &snap) {
+    ctx->cur_e = snap.cur_e;
+    ctx->cur_a = snap.cur_a;
+    if (snap.backup && ctx->pinned_e) HIP_TRY(hipMemcpyAsync(ctx->d_state + 4 * ctx->cur_e, ctx->d_state + 8, sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (snap.backup && ctx->pinned_a) HIP_TRY(hipMemcpyAsync(ctx->d_state + 4 * ctx->cur_a + 1, ctx->d_state + 9, 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return RT_DP_OK;
+}
+
+// A hand-over was given up on while the batch ran (s is idle): registers back to where they were, beat segments again
+// in the owning shape.  The caller waits for s afterwards.
+int beats_again(rt_dp_ctx *ctx, const rt_dp_op_batch *in, const rt_dp_result_batch *out, hipStream_t s, const RegSnapshot &snap) {
+    int rc = regs_restore(ctx, s, snap);
+    if (rc != RT_DP_OK) return rc;
+    ++ctx->chain_fallbacks;
+    return launch_beats(ctx, in, out, s, true);
 }
 
 // Enqueue the kernels of one batch whose arrays are all device pointers.
@@ -288,32 +410,7 @@ int launch_device(rt_dp_ctx *ctx, const rt_dp_op_batch *in, const rt_dp_result_b
         }
         return RT_DP_OK;
     }
-    if (n_euc || n_ang) {  // (16-byte alignment of a / b: check_batch, before anything was enqueued)
-        // A batch that is being captured into a graph runs again later with the arguments of today: the hand-over
-        // words of the chained kernels are told apart by a per-launch number, which a replay would repeat, so the
-        // captured kernels are the ones that own whole pairs and need no workspace; and the registers stay at the
-        // address the graph holds.
-        const bool captured = is_capturing(s);
-        if (n_euc) {
-            if (captured) ctx->pinned_e = true;
-            VecArgs a{in->euc.a, in->euc.b, in->euc.ctl, out->euc.accumulator, nullptr, ctx->d_state + 4 * ctx->cur_e, ctx->d_state + 4 * (ctx->cur_e ^ 1)};
-            int rc = captured ? RT_DP_OK : chain_for(ctx, n_euc, s, a);
-            if (rc != RT_DP_OK) return rc;
-            HIP_TRY(launch_euclid(a, n_euc, ctx->tuning, s));
-            rc = commit_state(ctx, ctx->cur_e, ctx->pinned_e, 0, 1, s);
-            if (rc != RT_DP_OK) return rc;
-        }
-        if (n_ang) {
-            if (captured) ctx->pinned_a = true;
-            VecArgs a{in->ang.a, in->ang.b, in->ang.ctl, out->ang.dot_product, out->ang.norm, ctx->d_state + 4 * ctx->cur_a + 1,
-                      ctx->d_state + 4 * (ctx->cur_a ^ 1) + 1};
-            int rc = captured ? RT_DP_OK : chain_for(ctx, n_ang, s, a);
-            if (rc != RT_DP_OK) return rc;
-            HIP_TRY(launch_angular(a, n_ang, ctx->tuning, s));
-            rc = commit_state(ctx, ctx->cur_a, ctx->pinned_a, 1, 2, s);
-            if (rc != RT_DP_OK) return rc;
-        }
-    }
+    if (n_euc || n_ang) return launch_beats(ctx, in, out, s, false);
     return RT_DP_OK;
 }
 
@@ -433,19 +530,28 @@ int eval_host(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *out)
             }
         }
     }
-    int rc = launch_device(ctx, &din, &dout, ctx->stream);
+    RegSnapshot snap;
+    int rc = regs_snapshot(ctx, ctx->stream, snap);
+    if (rc == RT_DP_OK) rc = launch_device(ctx, &din, &dout, ctx->stream);
+    if (rc == RT_DP_OK) rc = chain_probe(ctx, ctx->stream);
     if (rc != RT_DP_OK) {
         (void)hipStreamSynchronize(ctx->stream);  // the staged copies must not outlive the call: the next one reuses the buffers
         return rc;
     }
-    if (pinned) {
-        if (out_total) HIP_TRY(hipMemcpyAsync(ctx->h_stage + in_total, ctx->d_stage + in_total, out_total, hipMemcpyDeviceToHost, ctx->stream));
+    for (int round = 0; round < 2; ++round) {  // a second round only behind a give-up of the chained beat kernels
+        if (pinned) {
+            if (out_total) HIP_TRY(hipMemcpyAsync(ctx->h_stage + in_total, ctx->d_stage + in_total, out_total, hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            for (auto &s : outs) HIP_TRY(hipMemcpyAsync(s.dst_host, ctx->d_stage + s.off, s.bytes, hipMemcpyDeviceToHost, ctx->stream));
+        }
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        for (auto &s : outs) memcpy(s.dst_host, ctx->h_stage + s.off, s.bytes);
-        return RT_DP_OK;
+        ctx->own_pending = false;
+        if (round == 1 || !chain_moved(ctx)) break;
+        rc = beats_again(ctx, &din, &dout, ctx->stream, snap);
+        if (rc != RT_DP_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     }
-    for (auto &s : outs) HIP_TRY(hipMemcpyAsync(s.dst_host, ctx->d_stage + s.off, s.bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (pinned)
+        for (auto &s : outs) memcpy(s.dst_host, ctx->h_stage + s.off, s.bytes);
     return RT_DP_OK;
 }
 
@@ -510,6 +616,9 @@ int rt_dp_create(const rt_dp_config *cfg, rt_dp_ctx **out) {
     ctx->tuning.wgs_per_cu = env_int("RT_DP_WGS_PER_CU", 0);
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->launched, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->own_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_chain_hdr, 256);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_chain_hdr, 0, 256, ctx->stream);
     if (e == hipSuccess) e = compact_static_init(dev);  // address of this GPU's copy of the allocation-free entry point's scratch
     if (e == hipSuccess) e = hipMalloc(&ctx->d_state, 12 * sizeof(float));
     if (e == hipSuccess) e = hipMemsetAsync(ctx->d_state, 0, 12 * sizeof(float), ctx->stream);
@@ -529,6 +638,8 @@ void rt_dp_destroy(rt_dp_ctx *ctx) {
     if (ctx->launched_pending) (void)hipEventSynchronize(ctx->launched);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->launched) (void)hipEventDestroy(ctx->launched);
+    if (ctx->own_done) (void)hipEventDestroy(ctx->own_done);
+    if (ctx->d_chain_hdr) (void)hipFree(ctx->d_chain_hdr);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->d_stream) (void)hipFree(ctx->d_stream);
@@ -559,9 +670,16 @@ int rt_dp_launch(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *o
     if (s == ctx->stream) {
         rc = join_caller_stream(ctx, false);
         if (rc != RT_DP_OK) return rc;
+    } else if (beats && ctx->own_pending && !is_capturing(s)) {
+        // beat batches are still queued on the context's own stream: this one shares their registers and hand-over
+        // words, so it goes behind them
+        HIP_TRY(hipEventRecord(ctx->own_done, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(s, ctx->own_done, 0));
+        ctx->own_pending = false;
     }
     rc = launch_device(ctx, in, out, s);
     if (rc != RT_DP_OK) return rc;
+    if (s == ctx->stream && beats) ctx->own_pending = true;
     if (s != ctx->stream && beats) {
         // the registers were read and written on the caller's stream: remember where, unless the stream is being
         // captured into a graph (an event recorded there cannot be waited for from outside the graph)
@@ -612,8 +730,11 @@ int rt_dp_tile_unpack(rt_dp_ctx *ctx, const void *tiled, void *const *arrays, ui
 int rt_dp_synchronize(rt_dp_ctx *ctx) {
     if (!ctx) return fail(RT_DP_ENULL, "rt_dp_synchronize: ctx is NULL");
     DeviceGuard guard(ctx->device);
+    int rc = join_caller_stream(ctx, true);  // batches that rt_dp_launch put on a caller stream count as well
+    if (rc != RT_DP_OK) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return RT_DP_OK;
+    ctx->own_pending = false;
+    return chain_verdict(ctx, ctx->stream);
 }
 
 int rt_dp_eval_ctx(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch *out) {
@@ -627,9 +748,20 @@ int rt_dp_eval_ctx(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch 
         // synchronous entry point waits for the whole device before it reads them.
         HIP_TRY(hipDeviceSynchronize());
         ctx->launched_pending = false;  // whatever ran on a caller stream has finished
-        rc = launch_device(ctx, in, out, ctx->stream);
+        ctx->own_pending = false;
+        rc = chain_verdict(ctx, ctx->stream);  // batches launched asynchronously before this one: their failure is theirs
+        if (rc != RT_DP_OK) return rc;
+        RegSnapshot snap;
+        rc = regs_snapshot(ctx, ctx->stream, snap);
+        if (rc == RT_DP_OK) rc = launch_device(ctx, in, out, ctx->stream);
+        if (rc == RT_DP_OK) rc = chain_probe(ctx, ctx->stream);
         if (rc != RT_DP_OK) return rc;
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (chain_moved(ctx)) {  // a hand-over between workgroups was given up on: the same beats again, without hand-overs
+            rc = beats_again(ctx, in, out, ctx->stream, snap);
+            if (rc != RT_DP_OK) return rc;
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
         return RT_DP_OK;
     }
     rc = join_caller_stream(ctx, false);
@@ -656,6 +788,9 @@ int rt_dp_get_accum(rt_dp_ctx *ctx, float acc[3]) {
     int rc = join_caller_stream(ctx, true);
     if (rc != RT_DP_OK) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->own_pending = false;
+    rc = chain_verdict(ctx, ctx->stream);
+    if (rc != RT_DP_OK) return rc;
     float h[8];
     HIP_TRY(hipMemcpy(h, ctx->d_state, sizeof h, hipMemcpyDeviceToHost));
     acc[0] = h[4 * ctx->cur_e];
@@ -714,6 +849,7 @@ static int bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt_dp_
     } else {
         HIP_TRY(hipDeviceSynchronize());  // the records may still be in production on a caller stream
         ctx->launched_pending = false;
+        ctx->own_pending = false;
     }
 
     auto grow = [&](char *&buf, size_t &have, size_t want) -> int {
@@ -752,7 +888,7 @@ static int bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt_dp_
         for (uint64_t off = 0; off < n; off += chunk) {
             const uint64_t m = (n - off < chunk) ? (n - off) : chunk;
             HIP_TRY(stream_chain_eval(in_words + off * 84, m, first, ctx->extended ? 1 : 0, out_words + off * 21, ctx->d_stream, ctx->d_state + 4 * c,
-                                      ctx->d_state + 4 * (c ^ 1), &sticky, s));
+                                      ctx->d_state + 4 * (c ^ 1), &sticky, s, ctx->debug_chain_skip));
             if (ctx->extended) c ^= 1;
         }
         rc = pinned_words(ctx);
@@ -765,19 +901,30 @@ static int bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt_dp_
         HIP_TRY(hipMemcpyAsync(seen, sticky, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         const bool bad = seen[1] != 0;
+        const bool gave_up = seen[0] != 0;
         ctx->stream_giveups += seen[0];
-        if (bad) {  // the registers keep their values from before the call
+        if (bad || gave_up) {  // the registers get their values from before the call back
             c = home_a;
-            HIP_TRY(hipMemcpy(ctx->d_state + 4 * c, ctx->d_state + 8, 4 * sizeof(float), hipMemcpyDeviceToDevice));
+            HIP_TRY(hipMemcpyAsync(ctx->d_state + 4 * c, ctx->d_state + 8, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
         }
         if (ctx->extended) {
             // all three registers are in copy c now; a register whose address a graph holds goes back to that address
-            if (ctx->pinned_e && c != home_e) HIP_TRY(hipMemcpy(ctx->d_state + 4 * home_e, ctx->d_state + 4 * c, sizeof(float), hipMemcpyDeviceToDevice));
+            // (copies on s, which is idle: whatever the context launches next is ordered behind them)
+            if (ctx->pinned_e && c != home_e) HIP_TRY(hipMemcpyAsync(ctx->d_state + 4 * home_e, ctx->d_state + 4 * c, sizeof(float), hipMemcpyDeviceToDevice, s));
             if (!ctx->pinned_e) ctx->cur_e = c;
-            if (ctx->pinned_a && c != home_a) HIP_TRY(hipMemcpy(ctx->d_state + 4 * home_a + 1, ctx->d_state + 4 * c + 1, 2 * sizeof(float), hipMemcpyDeviceToDevice));
+            if (ctx->pinned_a && c != home_a) HIP_TRY(hipMemcpyAsync(ctx->d_state + 4 * home_a + 1, ctx->d_state + 4 * c + 1, 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
             if (!ctx->pinned_a) ctx->cur_a = c;
         }
         if (bad) return fail(RT_DP_EOPCODE, "the record stream holds an opcode > 3; the RTL's opcode field is 2 bits wide");
+        if (gave_up) {
+            // a wave waited in vain for the running sums of the waves before it: the two-pass form has no such wait and
+            // delivers the same records
+            ++ctx->chain_fallbacks;
+            ctx->stream_mode = 2;
+            const int rc2 = bundles_device(ctx, d_in, d_out, n, true, pinned_out, copied);
+            ctx->stream_mode = 3;
+            return rc2;
+        }
         return RT_DP_OK;
     }
     if (ctx->stream_mode == 2 || (ctx->stream_mode == 0 && aligned16)) {
@@ -821,13 +968,14 @@ static int bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt_dp_
         const uint32_t bad = *reinterpret_cast<const uint32_t *>(ctx->h_words);
         if (bad) {  // the registers keep their values from before the call
             c = home_a;
-            if (ctx->extended && !one_piece) HIP_TRY(hipMemcpy(ctx->d_state + 4 * c, ctx->d_state + 8, 4 * sizeof(float), hipMemcpyDeviceToDevice));
+            if (ctx->extended && !one_piece) HIP_TRY(hipMemcpyAsync(ctx->d_state + 4 * c, ctx->d_state + 8, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
         }
         if (ctx->extended) {
             // all three registers are in copy c now; a register whose address a graph holds goes back to that address
-            if (ctx->pinned_e && c != home_e) HIP_TRY(hipMemcpy(ctx->d_state + 4 * home_e, ctx->d_state + 4 * c, sizeof(float), hipMemcpyDeviceToDevice));
+            // (copies on s, which is idle: whatever the context launches next is ordered behind them)
+            if (ctx->pinned_e && c != home_e) HIP_TRY(hipMemcpyAsync(ctx->d_state + 4 * home_e, ctx->d_state + 4 * c, sizeof(float), hipMemcpyDeviceToDevice, s));
             if (!ctx->pinned_e) ctx->cur_e = c;
-            if (ctx->pinned_a && c != home_a) HIP_TRY(hipMemcpy(ctx->d_state + 4 * home_a + 1, ctx->d_state + 4 * c + 1, 2 * sizeof(float), hipMemcpyDeviceToDevice));
+            if (ctx->pinned_a && c != home_a) HIP_TRY(hipMemcpyAsync(ctx->d_state + 4 * home_a + 1, ctx->d_state + 4 * c + 1, 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
             if (!ctx->pinned_a) ctx->cur_a = c;
         }
         if (bad) return fail(RT_DP_EOPCODE, "the record stream holds an opcode > 3; the RTL's opcode field is 2 bits wide");
@@ -894,10 +1042,18 @@ static int bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt_dp_
     VecArgs ea{ob.euc.a, ob.euc.b, ob.euc.ctl, rb.euc.accumulator, nullptr, nullptr, nullptr};
     VecArgs aa{ob.ang.a, ob.ang.b, ob.ang.ctl, rb.ang.dot_product, rb.ang.norm, nullptr, nullptr};
     HIP_TRY(stream_scatter(in_words, n, blockcnt, slot, ba, ta, ea, aa, s));
-    rc = launch_device(ctx, &ob, &rb, s);
+    RegSnapshot snap;
+    rc = regs_snapshot(ctx, s, snap);
+    if (rc == RT_DP_OK) rc = launch_device(ctx, &ob, &rb, s);
+    if (rc == RT_DP_OK) rc = chain_probe(ctx, s);
     if (rc != RT_DP_OK) return rc;
-    HIP_TRY(stream_gather(slot, n, ba, ta, ea, aa, ctx->extended ? 1 : 0, reinterpret_cast<uint32_t *>(d_out), s));
-    HIP_TRY(hipStreamSynchronize(s));
+    for (int round = 0; round < 2; ++round) {  // a second round only behind a give-up of the chained beat kernels
+        HIP_TRY(stream_gather(slot, n, ba, ta, ea, aa, ctx->extended ? 1 : 0, reinterpret_cast<uint32_t *>(d_out), s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (round == 1 || !chain_moved(ctx)) break;
+        rc = beats_again(ctx, &ob, &rb, s, snap);
+        if (rc != RT_DP_OK) return rc;
+    }
     return RT_DP_OK;
 }
 
@@ -1442,6 +1598,9 @@ int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value) {
     } else if (!strcmp(key, "vec_passes")) {
         if (value != 0 && value != 2 && value != 4 && value != 8) return fail(RT_DP_EINVAL, "vec_passes must be 0, 2, 4 or 8");
         ctx->tuning.vec_passes = value;
+    } else if (!strcmp(key, "debug_chain_skip")) {
+        if (value < -1) return fail(RT_DP_EINVAL, "debug_chain_skip must be -1 (off) or a workgroup index");
+        ctx->debug_chain_skip = value;
     } else {
         return fail(RT_DP_EINVAL, "unknown option '%s'", key);
     }
@@ -1462,11 +1621,11 @@ int rt_dp_get_option(rt_dp_ctx *ctx, const char *key, int *value) {
     else if (!strcmp(key, "vec_tile")) *value = ctx->tuning.vec_tile > 0 ? (ctx->tuning.vec_tile < 64 ? 64 : ctx->tuning.vec_tile) : 512;
     else if (!strcmp(key, "vec_chain_giveups")) {
         unsigned long long h = 0;
-        if (ctx->d_chain) {
-            HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(hipMemcpy(&h, ctx->d_chain, sizeof h, hipMemcpyDeviceToHost));
-        }
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(&h, ctx->d_chain_hdr, sizeof h, hipMemcpyDeviceToHost));
         *value = h > 0x7FFFFFFFull ? 0x7FFFFFFF : (int)h;
+    } else if (!strcmp(key, "chain_fallbacks")) {
+        *value = ctx->chain_fallbacks > 0x7FFFFFFFull ? 0x7FFFFFFF : (int)ctx->chain_fallbacks;
     } else if (!strcmp(key, "box_wgs_per_cu")) *value = resolved_residency(ctx->tuning, true);
     else if (!strcmp(key, "tri_wgs_per_cu")) *value = resolved_residency(ctx->tuning, false);
     else return fail(RT_DP_EINVAL, "unknown option '%s'", key);

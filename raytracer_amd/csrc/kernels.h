@@ -44,12 +44,13 @@ struct VecArgs {
     // zero when allocated and never cleared afterwards; a slot is valid for the launch whose `epoch` it carries.
     // NULL selects the shape that needs no workspace.
     unsigned long long *chain = nullptr;
+    unsigned long long *chain_header = nullptr;  // word 0 counts hand-overs that were given up on (never, unless a workgroup is lost or starved)
     uint32_t epoch = 0;
     uint32_t diag = 0;  // diagnostic shapes of the chained kernel (A/B only, results meaningless): 1 no accumulation walk, 2 no LDS stage either
+    uint32_t debug_skip = 0;  // test hook: workgroup debug_skip - 1 does not publish its running sums, and waits give up after 2^12 polls
 };
 
-// Workspace of the chained beat kernels for n beats (any PASSES): a 256-byte header (word 0 counts hand-overs that
-// were given up on, which never happens unless the device loses a workgroup) and 16 bytes per 128-beat tile.
+// Hand-over words of the chained beat kernels for n beats (any PASSES): 16 bytes per 128-beat tile.
 size_t vec_chain_bytes(uint64_t n);
 
 struct RayPrepArgs {
@@ -109,7 +110,7 @@ hipError_t stream_fused_fold(const StreamSideView &v, uint64_t n, const float *s
 size_t stream_chain_workspace(uint64_t capacity);
 hipError_t stream_chain_begin(char *workspace, hipStream_t s);
 hipError_t stream_chain_eval(const uint32_t *in, uint64_t n, uint64_t capacity, int extended, uint32_t *out, char *workspace, const float *state_in,
-                             float *state_out, const unsigned long long **sticky_out, hipStream_t s);
+                             float *state_out, const unsigned long long **sticky_out, hipStream_t s, int mute_wave = -1 /* test hook */);
 
 // hit-mask compaction behind a Quadbox batch (compact.hip); blockcnt [ceil(n/256)] u32, offsets64 likewise u64, total one u64.
 // tile_words 0: flags / tmin are plain arrays; kBoxOutWords: they point at their word's run in tile 0 of a tiled result buffer

@@ -20,7 +20,9 @@
 #include "ops.hpp"
 
 #include <cstdlib>
+#include <map>
 #include <mutex>
+#include <tuple>
 
 #pragma clang fp contract(off)
 
@@ -623,16 +625,19 @@ __global__ __launch_bounds__(256, (PASSES <= 4) ? 7 : 4) void k_vec(VecArgs args
 // Progress: a workgroup waits only for the workgroup with the next lower index, which was dispatched before it and
 // waits, if at all, for a still lower one; workgroup 0 never waits.  A pair spanning many tiles is a serial chain by
 // definition of the arithmetic and costs one walk per tile, one after the other.  The wait is bounded all the same
-// (a lost workgroup must not hang the device): after kChainSpins polls the lane counts a give-up in the workspace
-// header and goes on with +0.
+// (a lost workgroup must not hang the device, and dispatch in index order is what the hardware does, not something
+// the programming model promises): after kChainSpins polls the lane counts a give-up in the header word and goes on
+// with +0.  The host reads that word behind every launch it waits for and re-evaluates the segment in the owning
+// shape, which needs no hand-over, when it moved (api.cpp), so a give-up costs time, never a wrong bit.
 constexpr int kChainSpins = 1 << 20;  // about a second; the longest legitimate wait is tens of milliseconds
+constexpr int kChainSpinsDebug = 1 << 12;
 
 __device__ __forceinline__ unsigned long long chain_word(uint32_t epoch, float v) {
     return ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v);
 }
 
-__device__ __forceinline__ float chain_wait(unsigned long long *slot, uint32_t epoch, unsigned long long *header) {
-    for (int spin = 0; spin < kChainSpins; ++spin) {
+__device__ __forceinline__ float chain_wait(unsigned long long *slot, uint32_t epoch, unsigned long long *header, int spins) {
+    for (int spin = 0; spin < spins; ++spin) {
         const unsigned long long w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((uint32_t)(w >> 32) == epoch) return __uint_as_float((uint32_t)w);
         __builtin_amdgcn_s_sleep(4);
@@ -670,8 +675,9 @@ __global__ __launch_bounds__(256, (PASSES * EPL <= 16) ? 7 : 4) void k_vec_chain
     const int cnt = (left < (uint64_t)SUB) ? (int)left : SUB;
     const bool last_tile = (left <= (uint64_t)SUB);
     const int part = tid % LPB;  // which EPL elements of the beat
-    unsigned long long *const header = args.chain;
-    unsigned long long *const slots = args.chain + 32;  // behind the 256-byte header, two words per tile
+    unsigned long long *const header = args.chain_header;
+    unsigned long long *const slots = args.chain;  // two words per tile
+    const int spins = args.debug_skip ? kChainSpinsDebug : kChainSpins;
 
     // phase 1: tree sums of the tile's beats
     VT va[PASSES], vb[PASSES];
@@ -761,7 +767,7 @@ __global__ __launch_bounds__(256, (PASSES * EPL <= 16) ? 7 : 4) void k_vec_chain
         if (last_tile) {
             args.state_out[0] = canon_nan(acc0);
             if (!EUC) args.state_out[1] = canon_nan(acc1);
-        } else {
+        } else if (args.debug_skip == 0u || blockIdx.x + 1u != args.debug_skip) {
             __hip_atomic_store(slots + 2 * (uint64_t)blockIdx.x, chain_word(args.epoch, acc0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!EUC) __hip_atomic_store(slots + 2 * (uint64_t)blockIdx.x + 1, chain_word(args.epoch, acc1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -819,8 +825,8 @@ __global__ __launch_bounds__(256, (PASSES * EPL <= 16) ? 7 : 4) void k_vec_chain
             acc0 = args.state_in[0];
             if (!EUC) acc1 = args.state_in[1];
         } else if (((before >> 16) & 1u) == 0u) {
-            acc0 = chain_wait(slots + 2 * (uint64_t)(blockIdx.x - 1), args.epoch, header);
-            if (!EUC) acc1 = chain_wait(slots + 2 * (uint64_t)(blockIdx.x - 1) + 1, args.epoch, header);
+            acc0 = chain_wait(slots + 2 * (uint64_t)(blockIdx.x - 1), args.epoch, header, spins);
+            if (!EUC) acc1 = chain_wait(slots + 2 * (uint64_t)(blockIdx.x - 1) + 1, args.epoch, header, spins);
         }
         walk(0, acc0, acc1);
     }
@@ -833,7 +839,7 @@ __global__ __launch_bounds__(256, (PASSES * EPL <= 16) ? 7 : 4) void k_vec_chain
     }
 }
 
-size_t vec_chain_bytes(uint64_t n) { return 256 + ((n + 127) / 128) * 16; }
+size_t vec_chain_bytes(uint64_t n) { return 256 + ((n + 127) / 128) * 16; }  // (256 bytes of slack behind the last tile)
 
 // ------------------------------------------------------- ray pre-processing
 // The step in front of the datapath: the ray fields that the reference's software model
@@ -891,9 +897,6 @@ static inline int min_align(const void *const *ptrs, int count) {
 constexpr int kBoxWgsPerCu = 3, kTriWgsPerCu = 5, kEucWgsPerCu = 4, kVecWgsPerCu = 99;  // from sweeps on MI355X
 constexpr int kTiledWgsPerCu = 3;  // box and triangle kernels over the tiled layout
 
-enum { kSlotBox = 0, kSlotBoxDerive, kSlotTri, kSlotTriDerive, kSlotEuc, kSlotAng, kSlotEucChain, kSlotAngChain,
-       kSlotBoxTiled, kSlotBoxTiledDerive, kSlotTriTiled, kSlotTriTiledDerive, kSlots };
-
 static unsigned residency_lds_guess(int w, unsigned static_lds) {
     // gfx950 hands out LDS in granules of 1280 bytes, 128 of them per CU (measured: the plateaus of the
     // kernel time against the requested size end at 20480, 23040, 26880, 32000, 40960 and 53760 bytes)
@@ -902,10 +905,12 @@ static unsigned residency_lds_guess(int w, unsigned static_lds) {
 }
 
 // The granule above is a measurement, not an architectural promise, so the size is verified with the runtime's
-// occupancy query once per (kernel, residency): if the guess does not yield exactly `w` resident workgroups, sizes
-// between the share of w + 1 and the share of w workgroups are tried until one does; failing that, the measured size
-// stays in use.  `achieved` is the query's answer for the size in use, so a caller can see a cap that did not take.
+// occupancy query once per (device, kernel, residency): if the guess does not yield exactly `w` resident workgroups,
+// sizes between the share of w + 1 and the share of w workgroups are tried until one does; failing that, the measured
+// size stays in use.  `achieved` is the query's answer for the size in use, so a caller can see a cap that did not take.
 struct Residency { unsigned lds; int achieved; };
+
+constexpr unsigned kMaxLdsPerWorkgroup = 65536u;  // static + dynamic; more would need a function attribute
 
 static Residency resolve_residency(const void *kernel, int w, unsigned static_lds) {
     auto occupancy = [&](unsigned lds) -> int {
@@ -913,54 +918,60 @@ static Residency resolve_residency(const void *kernel, int w, unsigned static_ld
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, 256, lds) != hipSuccess) { (void)hipGetLastError(); return -1; }
         return blocks;
     };
-    const unsigned guess = residency_lds_guess(w, static_lds);
+    const unsigned room = kMaxLdsPerWorkgroup > static_lds ? kMaxLdsPerWorkgroup - static_lds : 0u;
+    unsigned guess = residency_lds_guess(w, static_lds);
+    if (guess > room) guess = room;  // the kernel's own LDS leaves less than the share: the launch must stay launchable
     int got = occupancy(guess);
     if (got == w || got < 0) return {guess, got < 0 ? w : got};  // query unavailable: keep the measured size
     const unsigned total = 160u * 1024u;
     unsigned lo = total / (unsigned)(w + 1), hi = total / (unsigned)w;
-    if (hi > 65536u) hi = 65536u;  // more dynamic LDS per workgroup would need a function attribute
+    if (hi > kMaxLdsPerWorkgroup) hi = kMaxLdsPerWorkgroup;
     for (unsigned size = hi; size + 1 > lo && size >= 256u; size -= 256u) {
         const unsigned lds = size > static_lds ? size - static_lds : 0u;
-        if (occupancy(lds) == w) return {lds, w};
+        if (lds <= room && occupancy(lds) == w) return {lds, w};
     }
     return {guess, got};  // nothing in the window the hardware's 160 KiB allow: keep the measured size, report the query's answer
 }
 
-static Residency residency(const void *kernel, int slot, int wgs, int dflt, unsigned static_lds) {
+// `kernel` is the instantiation that is about to be launched: its own static LDS (hipFuncGetAttributes) counts against
+// the share, and the answer is cached per device, kernel and residency.
+static Residency residency(const void *kernel, int wgs, int dflt) {
     int w = (wgs > 0) ? wgs : dflt;
     if (w >= 99 || w <= 0 || w > 16) return {0u, 0};  // no cap
     if (w < 3) w = 3;
-    // one entry per (kernel slot, residency); filled on first use, read-mostly afterwards
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
     static std::mutex lock;
-    static Residency cache[kSlots][17];
-    static bool known[kSlots][17];
+    static std::map<std::tuple<int, const void *, int>, Residency> cache;  // filled on first use, read-mostly afterwards
     std::lock_guard<std::mutex> hold(lock);
-    if (!known[slot][w]) {
-        cache[slot][w] = resolve_residency(kernel, w, static_lds);
-        known[slot][w] = true;
-    }
-    return cache[slot][w];
+    const auto key = std::make_tuple(dev, kernel, w);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    hipFuncAttributes attr;
+    unsigned static_lds = 0u;
+    if (hipFuncGetAttributes(&attr, kernel) == hipSuccess) static_lds = (unsigned)attr.sharedSizeBytes;
+    else (void)hipGetLastError();
+    const Residency r = resolve_residency(kernel, w, static_lds);
+    cache.emplace(key, r);
+    return r;
 }
 
-
-
-static unsigned residency_lds(const void *kernel, int slot, int wgs, int dflt, unsigned static_lds) {
-    return residency(kernel, slot, wgs, dflt, static_lds).lds;
-}
+static unsigned residency_lds(const void *kernel, int wgs, int dflt) { return residency(kernel, wgs, dflt).lds; }
 
 // What the box / triangle launches of a large batch get with these settings: resident 256-thread workgroups per CU
 // (0 = no cap) as the occupancy query reports it for the dynamic-LDS size in use.
 int resolved_residency(const Tuning &t, bool box) {
-    if (box) return residency(reinterpret_cast<const void *>(&k_box<1, true>), kSlotBox, t.wgs_per_cu, kBoxWgsPerCu, 0u).achieved;
-    return residency(reinterpret_cast<const void *>(&k_tri<1, true>), kSlotTri, t.wgs_per_cu, kTriWgsPerCu, 0u).achieved;
+    if (box) return residency(reinterpret_cast<const void *>(&k_box<1, true>), t.wgs_per_cu, kBoxWgsPerCu).achieved;
+    return residency(reinterpret_cast<const void *>(&k_tri<1, true>), t.wgs_per_cu, kTriWgsPerCu).achieved;
 }
 
-#define RTDP_LAUNCH_OPS(KERNEL, ARGS, FIRST, N, V, NT, STREAM, LDS)                                             \
+#define RTDP_LAUNCH_OPS(KERNEL, ARGS, FIRST, N, V, NT, STREAM, WGS, DFLT)                                      \
     do {                                                                                              \
         const uint64_t groups_ = (N) / (V);                                                           \
         if (groups_) {                                                                                \
             const uint64_t blocks_ = (groups_ + 255) / 256;                                           \
-            hipLaunchKernelGGL((KERNEL<V, NT>), dim3((unsigned)blocks_), dim3(256), LDS, STREAM, ARGS, \
+            const unsigned lds_ = residency_lds(reinterpret_cast<const void *>(&KERNEL<V, NT>), WGS, DFLT); \
+            hipLaunchKernelGGL((KERNEL<V, NT>), dim3((unsigned)blocks_), dim3(256), lds_, STREAM, ARGS, \
                                (uint64_t)(FIRST), groups_);                                           \
         }                                                                                             \
         const uint64_t tail_ = (N) - groups_ * (V);                                                   \
@@ -970,25 +981,25 @@ int resolved_residency(const Tuning &t, bool box) {
         }                                                                                             \
     } while (0)
 
-template <bool NT> static void launch_box_v(const BoxArgs &a, uint64_t first, uint64_t n, int v, unsigned lds, hipStream_t s) {
-    if (v == 4) RTDP_LAUNCH_OPS(k_box, a, first, n, 4, NT, s, lds);
-    else if (v == 2) RTDP_LAUNCH_OPS(k_box, a, first, n, 2, NT, s, lds);
-    else RTDP_LAUNCH_OPS(k_box, a, first, n, 1, NT, s, lds);
+template <bool NT> static void launch_box_v(const BoxArgs &a, uint64_t first, uint64_t n, int v, int wgs, int dflt, hipStream_t s) {
+    if (v == 4) RTDP_LAUNCH_OPS(k_box, a, first, n, 4, NT, s, wgs, dflt);
+    else if (v == 2) RTDP_LAUNCH_OPS(k_box, a, first, n, 2, NT, s, wgs, dflt);
+    else RTDP_LAUNCH_OPS(k_box, a, first, n, 1, NT, s, wgs, dflt);
 }
-template <bool NT> static void launch_tri_v(const TriArgs &a, uint64_t first, uint64_t n, int v, unsigned lds, hipStream_t s) {
-    if (v == 4) RTDP_LAUNCH_OPS(k_tri, a, first, n, 4, NT, s, lds);
-    else if (v == 2) RTDP_LAUNCH_OPS(k_tri, a, first, n, 2, NT, s, lds);
-    else RTDP_LAUNCH_OPS(k_tri, a, first, n, 1, NT, s, lds);
+template <bool NT> static void launch_tri_v(const TriArgs &a, uint64_t first, uint64_t n, int v, int wgs, int dflt, hipStream_t s) {
+    if (v == 4) RTDP_LAUNCH_OPS(k_tri, a, first, n, 4, NT, s, wgs, dflt);
+    else if (v == 2) RTDP_LAUNCH_OPS(k_tri, a, first, n, 2, NT, s, wgs, dflt);
+    else RTDP_LAUNCH_OPS(k_tri, a, first, n, 1, NT, s, wgs, dflt);
 }
-template <bool NT> static void launch_box_derive_v(const BoxArgs &a, uint64_t first, uint64_t n, int v, unsigned lds, hipStream_t s) {
-    if (v == 4) RTDP_LAUNCH_OPS(k_box_derive, a, first, n, 4, NT, s, lds);
-    else if (v == 2) RTDP_LAUNCH_OPS(k_box_derive, a, first, n, 2, NT, s, lds);
-    else RTDP_LAUNCH_OPS(k_box_derive, a, first, n, 1, NT, s, lds);
+template <bool NT> static void launch_box_derive_v(const BoxArgs &a, uint64_t first, uint64_t n, int v, int wgs, int dflt, hipStream_t s) {
+    if (v == 4) RTDP_LAUNCH_OPS(k_box_derive, a, first, n, 4, NT, s, wgs, dflt);
+    else if (v == 2) RTDP_LAUNCH_OPS(k_box_derive, a, first, n, 2, NT, s, wgs, dflt);
+    else RTDP_LAUNCH_OPS(k_box_derive, a, first, n, 1, NT, s, wgs, dflt);
 }
-template <bool NT> static void launch_tri_derive_v(const TriArgs &a, uint64_t first, uint64_t n, int v, unsigned lds, hipStream_t s) {
-    if (v == 4) RTDP_LAUNCH_OPS(k_tri_derive, a, first, n, 4, NT, s, lds);
-    else if (v == 2) RTDP_LAUNCH_OPS(k_tri_derive, a, first, n, 2, NT, s, lds);
-    else RTDP_LAUNCH_OPS(k_tri_derive, a, first, n, 1, NT, s, lds);
+template <bool NT> static void launch_tri_derive_v(const TriArgs &a, uint64_t first, uint64_t n, int v, int wgs, int dflt, hipStream_t s) {
+    if (v == 4) RTDP_LAUNCH_OPS(k_tri_derive, a, first, n, 4, NT, s, wgs, dflt);
+    else if (v == 2) RTDP_LAUNCH_OPS(k_tri_derive, a, first, n, 2, NT, s, wgs, dflt);
+    else RTDP_LAUNCH_OPS(k_tri_derive, a, first, n, 1, NT, s, wgs, dflt);
 }
 
 // Operand and result streams are touched exactly once, so by default they carry the
@@ -1014,13 +1025,12 @@ hipError_t launch_box(const BoxArgs &args, uint64_t n, const Tuning &t, hipStrea
     for (int i = 0; i < 4; ++i) ptrs[kBoxFields + i] = args.tmin[i];
     ptrs[kBoxFields + 4] = args.flags;
     const int v = pick_v(t.ops_per_lane, min_align(ptrs, kBoxFields + 5), 1);  // measured with the residency cap: 1 beats 2 and 4 from 2^20 to 2^25 ops
-    const unsigned lds = derive ? residency_lds(reinterpret_cast<const void *>(&k_box_derive<1, true>), kSlotBoxDerive, t.wgs_per_cu, n >= (uint64_t(1) << 20) ? kBoxWgsPerCu : 99, 0u)
-                                : residency_lds(reinterpret_cast<const void *>(&k_box<1, true>), kSlotBox, t.wgs_per_cu, n >= (uint64_t(1) << 20) ? kBoxWgsPerCu : 99, 0u);
+    const int dflt = n >= (uint64_t(1) << 20) ? kBoxWgsPerCu : 99;
     if (derive) {
-        if (use_nt(t)) launch_box_derive_v<true>(args, 0, n, v, lds, stream);
-        else launch_box_derive_v<false>(args, 0, n, v, lds, stream);
-    } else if (use_nt(t)) launch_box_v<true>(args, 0, n, v, lds, stream);
-    else launch_box_v<false>(args, 0, n, v, lds, stream);
+        if (use_nt(t)) launch_box_derive_v<true>(args, 0, n, v, t.wgs_per_cu, dflt, stream);
+        else launch_box_derive_v<false>(args, 0, n, v, t.wgs_per_cu, dflt, stream);
+    } else if (use_nt(t)) launch_box_v<true>(args, 0, n, v, t.wgs_per_cu, dflt, stream);
+    else launch_box_v<false>(args, 0, n, v, t.wgs_per_cu, dflt, stream);
     return hipGetLastError();
 }
 
@@ -1033,13 +1043,11 @@ hipError_t launch_box_tiled(const float *in, uint32_t *out, uint64_t n, const Tu
     // measured (2^17 .. 2^26 ops): below 2^20 ops every wave that fits, 2^20 .. 2^21 five workgroups per CU (0.82 against 0.78 with three), from 2^21 three
     const int dflt = n >= (uint64_t(1) << 21) ? kTiledWgsPerCu : (n >= (uint64_t(1) << 20) ? 5 : 99);
     if (derive) {
-        const unsigned lds = residency_lds(reinterpret_cast<const void *>(&k_box_tiled<true, true>), kSlotBoxTiledDerive, t.wgs_per_cu, dflt, 0u);
-        if (use_nt(t)) hipLaunchKernelGGL((k_box_tiled<true, true>), grid, block, lds, stream, in, out, n);
-        else hipLaunchKernelGGL((k_box_tiled<false, true>), grid, block, lds, stream, in, out, n);
+        if (use_nt(t)) hipLaunchKernelGGL((k_box_tiled<true, true>), grid, block, residency_lds(reinterpret_cast<const void *>(&k_box_tiled<true, true>), t.wgs_per_cu, dflt), stream, in, out, n);
+        else hipLaunchKernelGGL((k_box_tiled<false, true>), grid, block, residency_lds(reinterpret_cast<const void *>(&k_box_tiled<false, true>), t.wgs_per_cu, dflt), stream, in, out, n);
     } else {
-        const unsigned lds = residency_lds(reinterpret_cast<const void *>(&k_box_tiled<true, false>), kSlotBoxTiled, t.wgs_per_cu, dflt, 0u);
-        if (use_nt(t)) hipLaunchKernelGGL((k_box_tiled<true, false>), grid, block, lds, stream, in, out, n);
-        else hipLaunchKernelGGL((k_box_tiled<false, false>), grid, block, lds, stream, in, out, n);
+        if (use_nt(t)) hipLaunchKernelGGL((k_box_tiled<true, false>), grid, block, residency_lds(reinterpret_cast<const void *>(&k_box_tiled<true, false>), t.wgs_per_cu, dflt), stream, in, out, n);
+        else hipLaunchKernelGGL((k_box_tiled<false, false>), grid, block, residency_lds(reinterpret_cast<const void *>(&k_box_tiled<false, false>), t.wgs_per_cu, dflt), stream, in, out, n);
     }
     return hipGetLastError();
 }
@@ -1051,13 +1059,11 @@ hipError_t launch_tri_tiled(const float *in, uint32_t *out, uint64_t n, const Tu
     // measured: below 2^21 ops uncapped (2^20: 0.91 against 0.80 with three workgroups per CU), 2^21 .. 2^22 five (0.84 against 0.77), from 2^22 three
     const int dflt = n >= (uint64_t(1) << 22) ? kTiledWgsPerCu : (n >= (uint64_t(1) << 21) ? 5 : 99);
     if (derive) {
-        const unsigned lds = residency_lds(reinterpret_cast<const void *>(&k_tri_tiled<true, true>), kSlotTriTiledDerive, t.wgs_per_cu, dflt, 0u);
-        if (use_nt(t)) hipLaunchKernelGGL((k_tri_tiled<true, true>), grid, block, lds, stream, in, out, n);
-        else hipLaunchKernelGGL((k_tri_tiled<false, true>), grid, block, lds, stream, in, out, n);
+        if (use_nt(t)) hipLaunchKernelGGL((k_tri_tiled<true, true>), grid, block, residency_lds(reinterpret_cast<const void *>(&k_tri_tiled<true, true>), t.wgs_per_cu, dflt), stream, in, out, n);
+        else hipLaunchKernelGGL((k_tri_tiled<false, true>), grid, block, residency_lds(reinterpret_cast<const void *>(&k_tri_tiled<false, true>), t.wgs_per_cu, dflt), stream, in, out, n);
     } else {
-        const unsigned lds = residency_lds(reinterpret_cast<const void *>(&k_tri_tiled<true, false>), kSlotTriTiled, t.wgs_per_cu, dflt, 0u);
-        if (use_nt(t)) hipLaunchKernelGGL((k_tri_tiled<true, false>), grid, block, lds, stream, in, out, n);
-        else hipLaunchKernelGGL((k_tri_tiled<false, false>), grid, block, lds, stream, in, out, n);
+        if (use_nt(t)) hipLaunchKernelGGL((k_tri_tiled<true, false>), grid, block, residency_lds(reinterpret_cast<const void *>(&k_tri_tiled<true, false>), t.wgs_per_cu, dflt), stream, in, out, n);
+        else hipLaunchKernelGGL((k_tri_tiled<false, false>), grid, block, residency_lds(reinterpret_cast<const void *>(&k_tri_tiled<false, false>), t.wgs_per_cu, dflt), stream, in, out, n);
     }
     return hipGetLastError();
 }
@@ -1085,32 +1091,35 @@ hipError_t launch_tri(const TriArgs &args, uint64_t n, const Tuning &t, hipStrea
     ptrs[kTriFields + 2] = args.t_denom;
     ptrs[kTriFields + 3] = args.hit;
     const int v = pick_v(t.ops_per_lane, min_align(ptrs, kTriFields + 4), 1);  // measured: never slower than 2, 5-20 % faster below 2^24 ops
-    const unsigned lds = derive ? residency_lds(reinterpret_cast<const void *>(&k_tri_derive<1, true>), kSlotTriDerive, t.wgs_per_cu, n >= (uint64_t(1) << 21) ? kTriWgsPerCu : 99, 0u)
-                                : residency_lds(reinterpret_cast<const void *>(&k_tri<1, true>), kSlotTri, t.wgs_per_cu, n >= (uint64_t(1) << 21) ? kTriWgsPerCu : 99, 0u);
+    const int dflt = n >= (uint64_t(1) << 21) ? kTriWgsPerCu : 99;
     if (derive) {
-        if (use_nt(t)) launch_tri_derive_v<true>(args, 0, n, v, lds, stream);
-        else launch_tri_derive_v<false>(args, 0, n, v, lds, stream);
-    } else if (use_nt(t)) launch_tri_v<true>(args, 0, n, v, lds, stream);
-    else launch_tri_v<false>(args, 0, n, v, lds, stream);
+        if (use_nt(t)) launch_tri_derive_v<true>(args, 0, n, v, t.wgs_per_cu, dflt, stream);
+        else launch_tri_derive_v<false>(args, 0, n, v, t.wgs_per_cu, dflt, stream);
+    } else if (use_nt(t)) launch_tri_v<true>(args, 0, n, v, t.wgs_per_cu, dflt, stream);
+    else launch_tri_v<false>(args, 0, n, v, t.wgs_per_cu, dflt, stream);
     return hipGetLastError();
 }
 
-template <bool EUC, bool NT> static void launch_vec_p(const VecArgs &args, uint64_t n, uint32_t tile, int passes, int walk, unsigned blocks, unsigned lds,
+// The residency cap of a beat launch is resolved for the instantiation that is launched (its static LDS differs with PASSES).
+#define RTDP_LAUNCH_VEC(KERNEL, BLOCKS, WGS, DFLT, STREAM, ...)                                                         \
+    hipLaunchKernelGGL((KERNEL), dim3(BLOCKS), dim3(kThreads), residency_lds(reinterpret_cast<const void *>(&KERNEL), WGS, DFLT), STREAM, __VA_ARGS__)
+
+template <bool EUC, bool NT> static void launch_vec_p(const VecArgs &args, uint64_t n, uint32_t tile, int passes, int walk, unsigned blocks, int wgs, int dflt,
                                                       hipStream_t stream) {
     switch (passes) {
-    case 2: hipLaunchKernelGGL((k_vec<EUC, NT, 2>), dim3(blocks), dim3(kThreads), lds, stream, args, n, tile, walk); break;
-    case 8: hipLaunchKernelGGL((k_vec<EUC, NT, 8>), dim3(blocks), dim3(kThreads), lds, stream, args, n, tile, walk); break;
-    default: hipLaunchKernelGGL((k_vec<EUC, NT, 4>), dim3(blocks), dim3(kThreads), lds, stream, args, n, tile, walk); break;
+    case 2: RTDP_LAUNCH_VEC((k_vec<EUC, NT, 2>), blocks, wgs, dflt, stream, args, n, tile, walk); break;
+    case 8: RTDP_LAUNCH_VEC((k_vec<EUC, NT, 8>), blocks, wgs, dflt, stream, args, n, tile, walk); break;
+    default: RTDP_LAUNCH_VEC((k_vec<EUC, NT, 4>), blocks, wgs, dflt, stream, args, n, tile, walk); break;
     }
 }
 
-template <bool EUC, bool NT> static void launch_chain_p(const VecArgs &args, uint64_t n, int passes, unsigned lds, hipStream_t stream) {
+template <bool EUC, bool NT> static void launch_chain_p(const VecArgs &args, uint64_t n, int passes, int wgs, int dflt, hipStream_t stream) {
     const uint64_t sub = (uint64_t)passes * (kThreads / (EUC ? 4 : 2));
     const unsigned blocks = (unsigned)((n + sub - 1) / sub);
     switch (passes) {
-    case 2: hipLaunchKernelGGL((k_vec_chain<EUC, NT, 2, 4>), dim3(blocks), dim3(kThreads), lds, stream, args, n); break;
-    case 8: hipLaunchKernelGGL((k_vec_chain<EUC, NT, 8, 4>), dim3(blocks), dim3(kThreads), lds, stream, args, n); break;
-    default: hipLaunchKernelGGL((k_vec_chain<EUC, NT, 4, 4>), dim3(blocks), dim3(kThreads), lds, stream, args, n); break;
+    case 2: RTDP_LAUNCH_VEC((k_vec_chain<EUC, NT, 2, 4>), blocks, wgs, dflt, stream, args, n); break;
+    case 8: RTDP_LAUNCH_VEC((k_vec_chain<EUC, NT, 8, 4>), blocks, wgs, dflt, stream, args, n); break;
+    default: RTDP_LAUNCH_VEC((k_vec_chain<EUC, NT, 4, 4>), blocks, wgs, dflt, stream, args, n); break;
     }
 }
 
@@ -1137,10 +1146,9 @@ template <bool EUC> static hipError_t launch_vec(const VecArgs &args, uint64_t n
         if ((n + 127) / 128 > 0x7FFFFFFFull) return hipErrorInvalidValue;
         // residency: the Euclidean shape (64 KiB of loads in flight per workgroup) is best with 4 workgroups per CU (0.824
         // of the HBM roof against 0.79 with the 6 its registers allow), the angular shape with all it can get
-        const unsigned lds = residency_lds(reinterpret_cast<const void *>(&k_vec_chain<EUC, true, EUC ? 8 : 4, 4>), EUC ? kSlotEucChain : kSlotAngChain, t.wgs_per_cu,
-                                           (EUC && passes == 8) ? kEucWgsPerCu : kVecWgsPerCu, 8192u + 64u);
-        if (use_nt(t)) launch_chain_p<EUC, true>(a2, n, passes, lds, stream);
-        else launch_chain_p<EUC, false>(a2, n, passes, lds, stream);
+        const int dflt = (EUC && passes == 8) ? kEucWgsPerCu : kVecWgsPerCu;
+        if (use_nt(t)) launch_chain_p<EUC, true>(a2, n, passes, t.wgs_per_cu, dflt, stream);
+        else launch_chain_p<EUC, false>(a2, n, passes, t.wgs_per_cu, dflt, stream);
         return hipGetLastError();
     }
     // defaults from interleaved sweeps on MI355X: sub-tiles of 512 beats for both opcodes; the Euclidean shape (loads
@@ -1152,11 +1160,9 @@ template <bool EUC> static hipError_t launch_vec(const VecArgs &args, uint64_t n
     if (tile < 64u) tile = 64u;
     const uint64_t blocks = (n + tile - 1) / tile;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const unsigned lds = residency_lds(reinterpret_cast<const void *>(&k_vec<EUC, true, EUC ? 8 : 4>), EUC ? kSlotEuc : kSlotAng, t.wgs_per_cu, kVecWgsPerCu,
-                                       8192u + 64u);  // the kernel's own LDS stays below 8 KiB
     const int walk = (t.variant == 21) ? 1 : (t.variant == 22) ? 2 : 0;  // A/B only: 21 plain walk everywhere, 22 look-ahead walk everywhere
-    if (use_nt(t)) launch_vec_p<EUC, true>(args, n, tile, passes, walk, (unsigned)blocks, lds, stream);
-    else launch_vec_p<EUC, false>(args, n, tile, passes, walk, (unsigned)blocks, lds, stream);
+    if (use_nt(t)) launch_vec_p<EUC, true>(args, n, tile, passes, walk, (unsigned)blocks, t.wgs_per_cu, kVecWgsPerCu, stream);
+    else launch_vec_p<EUC, false>(args, n, tile, passes, walk, (unsigned)blocks, t.wgs_per_cu, kVecWgsPerCu, stream);
     return hipGetLastError();
 }
 

@@ -1,6 +1,6 @@
 // rt_dp_replay: thin host driver that swaps the GPU evaluator in for simulated vectors.
 //
-//   rt_dp_replay <file.vec> [--dump out.vec] [--quiet]
+//   rt_dp_replay <file.vec> [--dump out.vec] [--quiet] [--gpus N]
 //
 // Reads a vector file (format: raytracer_amd/vecfile.py), feeds the input records
 // to a UnifiedDatapath instance the way the reference's testbench does
@@ -9,6 +9,9 @@
 // bit for bit with the expected record in the file.  Exit status 0 = all equal.
 // --dump writes the records that were computed, in the same format (e.g. to diff
 // against vectors captured from a Verilator run of the RTL).
+// --gpus N cuts the record stream into N parts where both accumulators are idle (rt_dp_shard_plan_records) and gives
+// every part its own thread and its own UnifiedDatapath instance on GPU r % rt_dp_device_count(); the parts' output
+// records, put together in order, are compared with the file like those of the single instance.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,6 +19,7 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "unified_datapath.hpp"
@@ -38,10 +42,13 @@ int main(int argc, char **argv) {
     }
     std::string dump;
     bool quiet = false;
+    int gpus = 1;
     for (int i = 2; i < argc; ++i) {
         if (!strcmp(argv[i], "--dump") && i + 1 < argc) dump = argv[++i];
         else if (!strcmp(argv[i], "--quiet")) quiet = true;
+        else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
     }
+    if (gpus < 1 || gpus > 64) { fprintf(stderr, "--gpus must be 1..64\n"); return 2; }
     std::ifstream f(argv[1]);
     if (!f) { fprintf(stderr, "cannot open %s\n", argv[1]); return 2; }
 
@@ -76,17 +83,50 @@ int main(int argc, char **argv) {
     try {
         RaytracerParams p;
         if (extended) p.support_euclidean = 16;
-        UnifiedDatapath dut(p);
-        dut.in.enqueueSeq(ins);
+        // one instance per part of the stream; with --gpus 1 this is the reference's single DUT
+        std::vector<uint64_t> cuts(gpus + 1);
+        if (rt_dp_shard_plan_records(ins.data(), ins.size(), (uint32_t)gpus, cuts.data()) != RT_DP_OK) throw std::runtime_error(rt_dp_last_error());
+        const int devices = rt_dp_device_count() > 0 ? rt_dp_device_count() : 1;
+        std::vector<std::vector<EnhancedOutputBundle>> part_out(gpus);
+        std::vector<std::string> part_err(gpus);
+        auto run_part = [&](int r) {
+            try {
+                UnifiedDatapath dut(p, gpus > 1 ? r % devices : -1);
+                dut.in.enqueueSeq(std::vector<EnhancedInputBundle>(ins.begin() + cuts[r], ins.begin() + cuts[r + 1]));
+                for (uint64_t i = cuts[r]; i < cuts[r + 1]; ++i) {
+                    dut.out.waitForValid();
+                    part_out[r].push_back(dut.out.bits());
+                    dut.out.step();
+                }
+            } catch (const std::exception &e) {
+                part_err[r] = e.what();
+                if (part_err[r].empty()) part_err[r] = "error";
+            }
+        };
+        if (gpus == 1) {
+            run_part(0);
+        } else {
+            std::vector<std::thread> threads;
+            for (int r = 0; r < gpus; ++r) threads.emplace_back(run_part, r);
+            for (auto &t : threads) t.join();
+        }
+        std::vector<EnhancedOutputBundle> computed;
+        for (int r = 0; r < gpus; ++r) {
+            if (!part_err[r].empty()) throw std::runtime_error("part " + std::to_string(r) + ": " + part_err[r]);
+            computed.insert(computed.end(), part_out[r].begin(), part_out[r].end());
+        }
+        if (gpus > 1 && !quiet) {
+            printf("parts:");
+            for (int r = 0; r < gpus; ++r) printf(" [%llu, %llu) on GPU %d", (unsigned long long)cuts[r], (unsigned long long)cuts[r + 1], r % devices);
+            printf("\n");
+        }
         std::ofstream out;
         if (!dump.empty()) {
             out.open(dump);
             out << "# computed by rt_dp_replay (" << rt_dp_version() << ")\nS " << name << " extended=" << extended << "\n";
         }
         for (size_t i = 0; i < ins.size(); ++i) {
-            dut.out.waitForValid();
-            const EnhancedOutputBundle got = dut.out.bits();
-            dut.out.step();
+            const EnhancedOutputBundle got = computed[i];
             uint32_t g[21], w[21];
             memcpy(g, &got, sizeof g);
             if (out.is_open()) {

@@ -427,7 +427,9 @@ __global__ __launch_bounds__(kFoldThreads) void k_stream_fold(StreamSideView v, 
 // Progress: a wave waits only for waves with a lower index, which were dispatched before it and wait, if at all, for still
 // lower ones; wave 0 never waits.  The wait is bounded all the same (a lost wave must not hang the device): after
 // kStreamSpins polls a give-up is counted in the header and the wave goes on with +0.
+// The host sees a non-zero count when the call returns and evaluates the stream again in the two-pass form (api.cpp).
 constexpr int kStreamSpins = 1 << 20;
+constexpr int kStreamSpinsDebug = 1 << 12;  // with the test hook that makes one wave withhold its sums
 
 struct StreamChain {
     unsigned long long *sticky;   // [0] give-ups, [1] an opcode > 3 was seen; cleared once per call
@@ -443,9 +445,9 @@ __device__ __forceinline__ unsigned long long stream_word(uint32_t state, float 
 // published.  Executed by the whole wave (uniform control flow).
 template <bool TWO>
 __device__ __forceinline__ void stream_look_back(const unsigned long long *w0, const unsigned long long *w1, long long b, float in0, float in1,
-                                                 int lane, unsigned long long *giveups, float &c0, float &c1) {
+                                                 int lane, unsigned long long *giveups, int spins, float &c0, float &c1) {
     long long top = b - 1;  // the nearest predecessor not yet known to be transparent
-    for (int spin = 0; spin < kStreamSpins; ++spin) {
+    for (int spin = 0; spin < spins; ++spin) {
         const long long idx = top - lane;
         uint32_t st = 2u;
         float v0 = in0, v1 = in1;  // in front of wave 0: the registers entering the stream
@@ -480,9 +482,11 @@ __device__ __forceinline__ void stream_look_back(const unsigned long long *w0, c
 template <bool TWO>
 __device__ __forceinline__ void stream_wave_fold(unsigned long long e, unsigned long long r, float s0, float s1, int lane, long long b,
                                                  unsigned long long *w0, unsigned long long *w1, const float *state_in, unsigned long long *giveups,
-                                                 float &res0, float &res1) {
+                                                 long long mute, float &res0, float &res1) {
+    const bool speak = (b != mute);  // test hook: wave `mute` never publishes, so that its successors' bounded wait runs out
+    const int spins = (mute >= 0) ? kStreamSpinsDebug : kStreamSpins;
     if (!e) {  // no beat of X here: the sum passes through
-        if (lane == 0) {
+        if (lane == 0 && speak) {
             __hip_atomic_store(w0 + b, stream_word(1u, 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (TWO) __hip_atomic_store(w1 + b, stream_word(1u, 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -495,22 +499,22 @@ __device__ __forceinline__ void stream_wave_fold(unsigned long long e, unsigned 
         // everything behind the first reset starts from +0, and what is left behind the last reset is the outgoing sum
         float a0 = 0.0f, a1 = 0.0f;
         stream_wave_walk<TWO>(e & ~head, r, s0, s1, lane, a0, a1, res0, res1);
-        if (lane == 0) {
+        if (lane == 0 && speak) {
             __hip_atomic_store(w0 + b, stream_word(2u, a0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (TWO) __hip_atomic_store(w1 + b, stream_word(2u, a1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     float c0, c1;
-    stream_look_back<TWO>(w0, w1, b, state_in[0], TWO ? state_in[1] : 0.0f, lane, giveups, c0, c1);
+    stream_look_back<TWO>(w0, w1, b, state_in[0], TWO ? state_in[1] : 0.0f, lane, giveups, spins, c0, c1);
     stream_wave_walk<TWO>(head, r, s0, s1, lane, c0, c1, res0, res1);
-    if (!r && lane == 0) {  // no reset in this wave: the outgoing sum is the incoming one plus all of its beats
+    if (!r && lane == 0 && speak) {  // no reset in this wave: the outgoing sum is the incoming one plus all of its beats
         __hip_atomic_store(w0 + b, stream_word(2u, c0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (TWO) __hip_atomic_store(w1 + b, stream_word(2u, c1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 __global__ __launch_bounds__(64) void k_stream_chain(const uint32_t *__restrict__ in, uint64_t n, int extended, uint32_t *__restrict__ out,
-                                                     StreamChain ch, const float *__restrict__ state_in) {
+                                                     StreamChain ch, const float *__restrict__ state_in, int mute) {
     __shared__ __align__(16) uint32_t s_rec[kWaveRecs * kRecIn];  // 21 KiB; re-used for the output records
     const int lane = threadIdx.x;
     const uint64_t r0 = (uint64_t)blockIdx.x * kWaveRecs;
@@ -538,9 +542,9 @@ __global__ __launch_bounds__(64) void k_stream_chain(const uint32_t *__restrict_
         const long long b = blockIdx.x;
         float e0 = 0.0f, unused = 0.0f, d0 = 0.0f, d1 = 0.0f;
         stream_wave_fold<false>(__ballot(op == 2u), __ballot(op == 2u && reset != 0u), sum0, 0.0f, lane, b, ch.word[0], nullptr, state_in, ch.sticky,
-                                e0, unused);
+                                (long long)mute, e0, unused);
         stream_wave_fold<true>(__ballot(op == 3u), __ballot(op == 3u && reset != 0u), sum0, sum1, lane, b, ch.word[1], ch.word[2], state_in + 1, ch.sticky,
-                               d0, d1);
+                               (long long)mute, d0, d1);
         if (op == 2u) w[16] = __float_as_uint(canon_nan(e0));
         if (op == 3u) { w[18] = __float_as_uint(canon_nan(d0)); w[19] = __float_as_uint(canon_nan(d1)); }
     }
@@ -612,7 +616,7 @@ hipError_t stream_chain_begin(char *workspace, hipStream_t s) { return hipMemset
 // One piece of n <= capacity records in one pass; state_in / state_out: {euclid, dot, norm} in front of / behind the piece.
 // *sticky_out: device address of {give-ups, opcode > 3 seen} (two 64-bit words) for the caller to read back.
 hipError_t stream_chain_eval(const uint32_t *in, uint64_t n, uint64_t capacity, int extended, uint32_t *out, char *workspace, const float *state_in,
-                             float *state_out, const unsigned long long **sticky_out, hipStream_t s) {
+                             float *state_out, const unsigned long long **sticky_out, hipStream_t s, int mute_wave) {
     size_t piece = 0;
     const StreamChain ch = stream_chain_layout(workspace, capacity, &piece);
     const uint64_t waves = (n + 63) / 64;
@@ -622,7 +626,7 @@ hipError_t stream_chain_eval(const uint32_t *in, uint64_t n, uint64_t capacity, 
         hipError_t e = hipMemsetAsync(ch.last, 0, piece, s);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_stream_chain, dim3((unsigned)waves), dim3(64), 0, s, in, n, extended, out, ch, state_in);
+    hipLaunchKernelGGL(k_stream_chain, dim3((unsigned)waves), dim3(64), 0, s, in, n, extended, out, ch, state_in, mute_wave);
     if (extended) {
         hipLaunchKernelGGL(k_stream_chain_last, dim3((unsigned)((waves + 1023) / 1024)), dim3(1024), 0, s, ch, (uint32_t)waves);
         hipLaunchKernelGGL(k_stream_chain_state, dim3(1), dim3(64), 0, s, ch, state_in, state_out);

@@ -31,6 +31,9 @@ tri, k = gen.tri_ops(5003, seed=2, edge_frac=0.2)
 ea, eb, ectl, _ = gen.vec_beats(700, 16, seed=3, edge_frac=0.1)
 qa, qb, qctl, _ = gen.vec_beats(500, 8, seed=4, edge_frac=0.1)
 plan = shard.plan(k.shape[0], box[0].shape[0], ectl, qctl, world)[rank]
+# the planner of the C ABI (what a C host driver with one thread per GPU calls) makes the same cuts
+from raytracer_amd import capi
+assert capi.shard_plan(k.shape[0], box[0].shape[0], ectl, qctl, world)[rank] == plan
 
 s, e = plan["box"]
 tmin, flags = O.box_soa([f[s:e] for f in box])
