@@ -311,29 +311,67 @@ def run(ctx, batch, steps, warmup, dist):
     return wall, dev_ms
 
 
+def run_pack(ctx, arrays, tiled, n, steps, warmup, dist):
+    """rt_dp_tile_pack of `arrays` into `tiled`, timed like a batch: (wall seconds for `steps` calls, max over ranks; device ms per call)."""
+    stream = bench_stream()
+    for _ in range(warmup):
+        ctx.tile_pack(arrays, tiled, n, stream.cuda_stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for _ in range(steps):
+        ctx.tile_pack(arrays, tiled, n, stream.cuda_stream)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    wall = dist_util.max_over_ranks(time.perf_counter() - t0)
+    return wall, e0.elapsed_time(e1) / steps
+
+
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
 
 
-def roofline(counts, dev_ms, measured_format=True, layout="plain"):
+OPCODE = {"tri": 0, "box": 1, "euclid": 2, "angular": 3}
+
+
+def kernel_names(ctx, batch, counts):
+    """The kernel the library runs for every segment of `batch`, as rocprofv3 names it (rt_dp_kernel_name)."""
+    return {k: ctx.kernel_name(batch, OPCODE[k]) for k in counts}
+
+
+def roofline(counts, dev_ms, measured_format=True, layout="plain", names=None):
     """The launch against the HBM roof.  `achieved` is live (algorithmic bytes / HIP-event time of this run); `traffic` and
     `valu_issue_fraction` are NOT measured in this run: they are the per-unit figures of the committed rocprofv3 --pmc passes
-    (profiles/traffic.json) scaled to this launch, and `traffic_source` says so."""
+    (profiles/traffic.json) scaled to this launch, and `traffic_source` says so.  The passes are looked up by KERNEL NAME:
+    `names` holds the kernel the library resolved for each segment of this launch, and a segment whose kernel has no
+    committed pass (the library picks another kernel than the one that was measured) makes traffic null and the source
+    "stale", naming the kernel."""
     algo = sum(BYTES[k] * v for k, v in counts.items())
     gbs = algo / (dev_ms * 1e-3) / 1e9
     r = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
          "traffic": None, "valu_issue_fraction": None, "traffic_source": None}
-    if measured_format and os.path.exists(TRAFFIC_FILE):   # the committed passes measured the plain operand format
+    if names:
+        r["kernels"] = names
+    if measured_format and names and os.path.exists(TRAFFIC_FILE):   # the committed passes measured the operand format without derived fields
         try:
             per_unit = json.load(open(TRAFFIC_FILE))
-            key = lambda k: k + "_tiled" if layout == "tiled" and k in ("box", "tri") else k   # the tiled kernels have passes of their own
-            r["traffic"] = int(sum(per_unit[key(k)]["hbm_bytes_per_unit"] * v for k, v in counts.items()))
+            by_kernel = {v["kernel"]: v for k, v in per_unit.items() if isinstance(v, dict) and "kernel" in v}
+            missing = [names[k] for k in counts if names[k] not in by_kernel]
+            if missing:
+                r["traffic_source"] = "stale: profiles/traffic.json holds no counter pass for %s" % ", ".join(sorted(set(missing)))
+                return r
+            r["traffic"] = int(sum(by_kernel[names[k]]["hbm_bytes_per_unit"] * v for k, v in counts.items()))
             if len(counts) == 1:
                 (k,) = counts.keys()
-                r["valu_issue_fraction"] = per_unit[key(k)].get("valu_issue_fraction")
-            r["traffic_source"] = "profiles/traffic.json (%s), per-unit counter figures x the units of this launch; not re-measured in this run" % per_unit.get(
+                r["valu_issue_fraction"] = by_kernel[names[k]].get("valu_issue_fraction")
+            r["traffic_source"] = "profiles/traffic.json (%s), per-unit counter figures of the same kernels x the units of this launch; not re-measured in this run" % per_unit.get(
                 "_source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes")
-        except Exception:
-            pass
+        except Exception as e:  # noqa: BLE001
+            r["traffic_source"] = "unavailable: %s" % e
     return r
 
 
@@ -643,7 +681,7 @@ def strong_mixed_measure(a, ctx, world, rank, dev, dist, log2_total, steps, warm
     block = {"value": round(units * steps / wall, 1), "unit": "ops/s", "ms_per_step": round(wall / steps * 1e3, 4), "kernel_ms": round(dev_ms, 4),
              "steps": steps, "warmup": warmup, "scaling": "strong", "units_whole_job": units, "units_this_gpu": sum(counts.values()),
              "workload": "mixed: 2^%d-unit opcode-sorted stream (a quarter per opcode), cut by shard.plan into %d pair-aligned shard(s), no collective" % (log2_total, world),
-             "layout": layout, "roofline": roofline(counts, dev_ms, True, layout)}
+             "layout": layout, "roofline": roofline(counts, dev_ms, True, layout, kernel_names(ctx, batch, counts))}
     if a.verify:
         # the shards' results, put together in rank order, must be the whole stream's results (computed on rank 0 in one batch)
         ctx.reset()
@@ -732,6 +770,22 @@ def main():
         dist_util.shutdown()
         return
 
+    if a.only == "pack":   # rt_dp_tile_pack alone: what a caller with separate arrays pays for the tiled layout
+        fields = synth.box_stream(n, 20241008, dev)
+        tiled_buf = torch.empty(capi.tiled_words(n, capi.BOX_TILE_IN_WORDS), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        wall, dev_ms = run_pack(ctx, fields, tiled_buf, n, a.steps, a.warmup, dist)
+        moved = 2 * 4 * len(fields) * n
+        if rank == 0:
+            print(json.dumps({"metric": "ops/s packed (rt_dp_tile_pack, 34 operand arrays -> tiled box segment)", "value": round(n * world * a.steps / wall, 1), "unit": "ops/s",
+                              "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(wall / a.steps * 1e3, 4), "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": {"workload": "pack: %d box ops per GPU" % n},
+                              "roofline": {"bound": "hbm", "achieved": round(moved / dev_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": round(moved / dev_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(dev_ms, 4)}, "cpu_baseline": None}), flush=True)
+        ctx.close()
+        dist_util.shutdown()
+        return
+
     which = [a.only] if a.only else ["box", "tri", "euclid", "angular", "mixed"]
     only_edge = 0.0
     if a.only in ("box_edge", "tri_edge"):      # the edge-class stream of one opcode as the headline
@@ -756,7 +810,7 @@ def main():
         units = sum(counts.values())
         results[name] = {"value": units * world * a.steps / wall, "ms_per_step": wall / a.steps * 1e3, "scaling": "weak",
                          "kernel_ms": dev_ms, "units_per_gpu": units, "layout": a.layout if name in ("box", "tri", "mixed") else "plain",
-                         "roofline": roofline(counts, dev_ms, plain, a.layout)}
+                         "roofline": roofline(counts, dev_ms, plain, a.layout, kernel_names(ctx, batch, counts))}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and "box" in batches:
@@ -785,9 +839,21 @@ def main():
             wall, dev_ms = run(ctx, ob, a.steps, a.warmup, dist)
             results[name + "_" + other] = {"value": counts[name] * world * a.steps / wall, "ms_per_step": wall / a.steps * 1e3, "scaling": "weak",
                                            "kernel_ms": dev_ms, "units_per_gpu": counts[name], "layout": other,
-                                           "roofline": roofline(counts, dev_ms, plain, other)}
+                                           "roofline": roofline(counts, dev_ms, plain, other, kernel_names(ctx, ob, counts))}
             del ob
             torch.cuda.empty_cache()
+        if a.layout == "tiled":
+            # what a caller with one array per operand pays to get the tiled layout: rt_dp_tile_pack, one pass, operand bytes in + out
+            for name, arrays, tiled_buf in (("box", batches["box"][0].box_fields, batches["box"][0].box_tiled[0]),
+                                            ("tri", list(batches["tri"][0].tri_fields) + [batches["tri"][0].tri_k], batches["tri"][0].tri_tiled[0])):
+                wall, dev_ms = run_pack(ctx, arrays, tiled_buf, n, a.steps, a.warmup, dist)
+                moved = 2 * 4 * len(arrays) * n
+                results["pack_" + name] = {"value": n * world * a.steps / wall, "ms_per_step": wall / a.steps * 1e3, "scaling": "weak", "kernel_ms": dev_ms,
+                                           "units_per_gpu": n, "layout": "plain -> tiled",
+                                           "roofline": {"bound": "hbm", "achieved": round(moved / dev_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                        "frac": round(moved / dev_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
+                                                        "bytes_per_op": 2 * 4 * len(arrays), "kernels": {name: "rtdp::k_tile_copy16<true>"},
+                                                        "note": "rt_dp_tile_pack: %d operand words per op read from separate arrays and written to the tiled buffer" % len(arrays)}}
         for name in ("box", "tri"):
             batch, counts = batches[name]
             if name == "box":
@@ -811,7 +877,7 @@ def main():
             torch.cuda.synchronize()
             wall, dev_ms = run(ctx, batch, a.steps, a.warmup, dist)
             results[name + "_edge"] = {"value": counts[name] * world * a.steps / wall, "ms_per_step": wall / a.steps * 1e3, "scaling": "weak",
-                                       "kernel_ms": dev_ms, "units_per_gpu": counts[name], "layout": a.layout, "roofline": roofline(counts, dev_ms, plain, a.layout),
+                                       "kernel_ms": dev_ms, "units_per_gpu": counts[name], "layout": a.layout, "roofline": roofline(counts, dev_ms, plain, a.layout, kernel_names(ctx, batch, counts)),
                                        "edge_classes": {"per_class": a.edge_per_class, "same_arrays_as": name,
                                                         "classes": synth.BOX_EDGE_CLASSES if name == "box" else synth.TRI_EDGE_CLASSES}}
         del batches, batch
@@ -851,7 +917,7 @@ def main():
     }
     if rank == 0:
         line["cpu_baseline"] = cpu
-        line["per_opcode"] = {k: {"value": round(v["value"], 1), "unit": "ops/s" if k.split("_")[0] in ("box", "tri", "mixed") else "beats/s",
+        line["per_opcode"] = {k: {"value": round(v["value"], 1), "unit": "ops/s" if k.split("_")[0] in ("box", "tri", "mixed", "pack") else "beats/s",
                                   "scaling": v["scaling"], "kernel_ms": round(v["kernel_ms"], 4), "units_per_gpu": v["units_per_gpu"],
                                   "layout": v.get("layout", "plain"), "roofline": v["roofline"], **({"edge_classes": v["edge_classes"]} if "edge_classes" in v else {})}
                               for k, v in results.items()}

@@ -614,8 +614,10 @@ int rt_dp_set_tuning(rt_dp_ctx *ctx, int ops_per_lane, int nontemporal, int vec_
  * pairs and searches for their boundaries; "chained": fixed tiles that hand their running sums on from one to the
  * next through a workspace inside the context -- and each opcode defaults to the one that measured faster (Euclidean
  * chained; angular owning, chained for segments of up to 2^23 beats); 23: owning for both (21 / 22: with one or the other form of its serial accumulation),
- * 27: chained for both, 24 / 25 diagnostic: chained without the accumulation / without the LDS stage either,
- * outputs meaningless).  "vec_tile" applies to the owning shape only.  Environment: RT_DP_VEC_PASSES,
+ * 27: chained for both, 28: the chained shape as a persistent workgroup whose waves split the work -- three load and
+ * sum the next tiles while the fourth accumulates the current one -- for both (measured slower on MI355X, 0.69 against
+ * 0.75 - 0.78 of the HBM roof for angular beats; an option, not a default); 24 / 25 diagnostic: chained without the
+ * accumulation / without the LDS stage either, outputs meaningless).  "vec_tile" applies to the owning shape only.  Environment: RT_DP_VEC_PASSES,
  * RT_DP_VARIANT.  "wgs_per_cu" (resident 256-thread workgroups per CU of the box / triangle / beat
  * kernels: 0 the measured per-kernel default, 3..16, 99 as many as fit; environment RT_DP_WGS_PER_CU).
  * "stream_mode" selects how rt_dp_eval_bundles_device works: 1 partitions the
@@ -637,6 +639,12 @@ int rt_dp_get_option(rt_dp_ctx *ctx, const char *key, int *value);
  * entry point evaluated a second time, without hand-overs, because of such a give-up.  All three stay 0 on a
  * healthy device.  "debug_chain_skip" (write only, for tests): workgroup k of the chained beat kernels does not
  * publish its running sums and waits are cut to 2^12 polls, so the give-up path can be exercised; -1 turns it off. */
+
+/* The kernel that rt_dp_launch / rt_dp_eval_ctx runs for the segment of `opcode` in this batch under the context's
+ * present tuning (outside graph capture), named as a profiler prints it, e.g. "rtdp::k_box_tiled<true, false>"; an
+ * empty string for an empty segment.  For harnesses that keep counter measurements per kernel and want to know
+ * whether they still describe what the library picks.  No counterpart in the reference.                        */
+int rt_dp_kernel_name(rt_dp_ctx *ctx, const rt_dp_op_batch *in, const rt_dp_result_batch *out, int opcode, char *buf, uint64_t len);
 
 const char *rt_dp_last_error(void);
 const char *rt_dp_version(void);

@@ -135,7 +135,7 @@ class KnnTree(C.Structure):
 EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize", "rt_dp_tile_pack", "rt_dp_tile_unpack",
            "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_get_option", "rt_dp_knn_euclid16", "rt_dp_knn_angular16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_box_compact", "rt_dp_box_compact_tiled", "rt_dp_box_compact_static", "rt_dp_beat_offsets_host", "rt_dp_pairs_to_beats", "rt_dp_beats_to_pairs", "rt_dp_bvh4_build_device", "rt_dp_knn_tree_build_device", "rt_dp_knn_home_leaf", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
            "rt_dp_knn_tree_leaves", "rt_dp_knn_tree_build_host", "rt_dp_knn_home_leaf_host", "rt_dp_bvh4_max_nodes", "rt_dp_bvh4_build_host",
-           "rt_dp_shard_plan", "rt_dp_shard_plan_records",
+           "rt_dp_shard_plan", "rt_dp_shard_plan_records", "rt_dp_kernel_name",
            "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
 
 
@@ -201,6 +201,7 @@ def load():
     L.rt_dp_knn_home_leaf_host.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.rt_dp_bvh4_max_nodes.argtypes = [C.c_uint32]
     L.rt_dp_bvh4_build_host.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
+    L.rt_dp_kernel_name.argtypes = [vp, C.POINTER(OpBatch), C.POINTER(ResultBatch), C.c_int, C.c_char_p, C.c_uint64]
     L.rt_dp_shard_plan.argtypes = [C.POINTER(C.c_uint64 * 4), vp, vp, C.c_uint32, C.c_uint32, C.POINTER(ShardRange)]
     L.rt_dp_shard_plan_records.argtypes = [vp, C.c_uint64, C.c_uint32, vp]
     L.rt_dp_last_error.restype = C.c_char_p
@@ -429,6 +430,13 @@ class Context:
         v = C.c_int(0)
         _check(self._L.rt_dp_get_option(self._h, key.encode(), C.byref(v)))
         return int(v.value)
+
+    def kernel_name(self, batch, opcode):
+        """Name (as rocprofv3 prints it) of the kernel a launch of `batch` runs for the segment of `opcode` (0..3)."""
+        batch.finalize()
+        buf = C.create_string_buffer(128)
+        _check(self._L.rt_dp_kernel_name(self._h, C.byref(batch.ob), C.byref(batch.rb), int(opcode), buf, 128))
+        return buf.value.decode()
 
     def eval_bundles_device(self, d_in, d_out):
         """Record stream resident in HBM: d_in int32 CUDA tensor [n, 84], d_out int32 CUDA tensor [n, 21]."""

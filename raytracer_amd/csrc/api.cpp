@@ -1584,10 +1584,49 @@ int rt_dp_bvh4_build_device(rt_dp_ctx *ctx, const float *tris, uint32_t n_tris, 
     return RT_DP_OK;
 }
 
+int rt_dp_kernel_name(rt_dp_ctx *ctx, const rt_dp_op_batch *in, const rt_dp_result_batch *out, int opcode, char *buf, uint64_t len) {
+    if (!ctx || !buf || len == 0) return fail(RT_DP_ENULL, "rt_dp_kernel_name: NULL argument");
+    if (opcode < 0 || opcode > 3) return fail(RT_DP_EOPCODE, "rt_dp_kernel_name: opcode %d", opcode);
+    int rc = check_batch(in, out);
+    if (rc != RT_DP_OK) return rc;
+    buf[0] = 0;
+    const uint64_t n = in->n[opcode];
+    if (n == 0) return RT_DP_OK;
+    const bool derive = (in->flags & RT_DP_F_DERIVE_RAY) != 0;
+    auto lanes = [](uintptr_t acc) { return (acc & 15u) == 0 ? 4 : ((acc & 7u) == 0 ? 2 : 1); };
+    if (opcode == RT_DP_OP_QUADBOX) {
+        const bool tiled = (in->flags & RT_DP_F_BOX_TILED) != 0;
+        uintptr_t acc = 0;
+        if (!tiled) {
+            BoxArgs a;
+            fill_box(a, in->box, out->box, derive);
+            for (int f = 0; f < kBoxFields; ++f) acc |= reinterpret_cast<uintptr_t>(a.in[f]);
+            for (int k = 0; k < 4; ++k) acc |= reinterpret_cast<uintptr_t>(a.tmin[k]);
+            acc |= reinterpret_cast<uintptr_t>(a.flags);
+        }
+        kernel_name_ops(true, tiled, derive, lanes(acc), ctx->tuning, buf, (size_t)len);
+    } else if (opcode == RT_DP_OP_TRIANGLE) {
+        const bool tiled = (in->flags & RT_DP_F_TRI_TILED) != 0;
+        uintptr_t acc = 0;
+        if (!tiled) {
+            TriArgs a;
+            fill_tri(a, in->tri, out->tri, derive);
+            for (int f = 0; f < kTriFields; ++f) acc |= reinterpret_cast<uintptr_t>(a.in[f]);
+            acc |= reinterpret_cast<uintptr_t>(a.k) | reinterpret_cast<uintptr_t>(a.t_num) | reinterpret_cast<uintptr_t>(a.t_denom) | reinterpret_cast<uintptr_t>(a.hit);
+        }
+        kernel_name_ops(false, tiled, derive, lanes(acc), ctx->tuning, buf, (size_t)len);
+    } else if (!ctx->extended) {
+        snprintf(buf, (size_t)len, "(memset: the baseline datapath has no distance ops)");
+    } else {
+        kernel_name_vec(opcode == RT_DP_OP_EUCLIDEAN, n, ctx->tuning, true, buf, (size_t)len);
+    }
+    return RT_DP_OK;
+}
+
 int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value) {
     if (!ctx || !key) return fail(RT_DP_ENULL, "rt_dp_set_option: NULL argument");
     if (!strcmp(key, "variant")) {
-        if (!(value == 0 || value == 10 || (value >= 21 && value <= 27 && value != 26))) return fail(RT_DP_EINVAL, "variant must be 0, 10, 21..25 or 27 (diagnostic shapes)");
+        if (!(value == 0 || value == 10 || (value >= 21 && value <= 28 && value != 26))) return fail(RT_DP_EINVAL, "variant must be 0, 10, 21..25, 27 or 28 (kernel shapes)");
         ctx->tuning.variant = value;
     } else if (!strcmp(key, "wgs_per_cu")) {
         if (!(value == 0 || value == 99 || (value >= 3 && value <= 16))) return fail(RT_DP_EINVAL, "wgs_per_cu must be 0 (default), 3..16, or 99 (no cap)");

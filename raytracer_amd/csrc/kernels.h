@@ -81,6 +81,10 @@ hipError_t launch_tile_unpack(const uint32_t *tiled, int count, uint64_t n, cons
 hipError_t launch_euclid(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
 int resolved_residency(const Tuning &t, bool box);  // workgroups per CU that large box / triangle batches run with (0: no cap), per the occupancy query
 hipError_t launch_angular(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream);
+// Names of the kernels a launch runs, as rocprofv3 prints them.  chain_ok: the launch is not being captured into a graph.
+// ops_per_lane_possible: 1, 2 or 4 by the common alignment of the segment's arrays (4, 8, 16 bytes).
+void kernel_name_vec(bool euclid, uint64_t n, const Tuning &t, bool chain_ok, char *buf, size_t len);
+void kernel_name_ops(bool box, bool tiled, bool derive, int ops_per_lane_possible, const Tuning &t, char *buf, size_t len);
 
 // Stream front-end (stream.hip): device-side stable partition of record streams by opcode.
 hipError_t stream_count_scan(const uint32_t *in, uint64_t n, uint32_t *blockcnt, uint32_t *totals_and_flag, hipStream_t s);

@@ -19,6 +19,7 @@
 // src/main/scala/raytracer_datapath/UnifiedDatapath.scala unless stated.
 #include "ops.hpp"
 
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -244,6 +245,43 @@ __global__ __launch_bounds__(256) void k_tri_tiled(const float *__restrict__ in,
 }
 
 // Plain arrays <-> tiled buffer, any number of 32-bit arrays up to kTileMaxArrays.
+//
+// A tile's run of one word is kTileOps contiguous words in the tiled buffer AND in the plain array, so the conversion is
+// a set of contiguous 32 KiB copies with 16-byte accesses.  A workgroup moves a quarter of a run (8 KiB: a lane's two
+// loads are issued before its first store); the (tile, word, quarter) index runs quarter-fastest, then word, so the
+// workgroups in flight write (pack) or read (unpack) the tiled buffer as one sequential stream.  Each byte is touched
+// once: nt hints on both sides.  Measured on MI355X, 34 arrays, fractions of the HBM peak over bytes read + written
+// (2^22 / 2^24 / 2^26 ops): whole runs per workgroup 0.72 at 2^24 whatever the residency; halves 0.775 (4 workgroups per
+// CU); quarters with 3 workgroups per CU 0.78 / 0.78 / 0.76; eighths 0.77 / 0.80 / 0.69 uncapped; tile-fastest order
+// 0.66 - 0.74.  (A first version guarded every load by the tile's live count: the compiler then waited for each load
+// before it issued the next, 0.53.)
+constexpr int kCopySplit = 4, kCopyWgsPerCu = 3;
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_tile_copy16(TileList l, uint32_t count, uint64_t n, uint32_t *__restrict__ tiled) {
+    constexpr int kChunks = kTileOps / 4 / 256 / kCopySplit;  // 16-byte chunks per lane: 2
+    const uint32_t part = blockIdx.x % kCopySplit, b = blockIdx.x / kCopySplit;
+    const uint64_t tile = b / count;
+    const uint32_t w = b % count;
+    uint32_t *__restrict__ plain = l.a[w] + tile * kTileOps;
+    uint32_t *__restrict__ run = tiled + (tile * count + w) * (uint64_t)kTileOps;
+    const uint64_t left = n - tile * kTileOps;
+    const uint32_t *src = PACK ? plain : run;
+    uint32_t *dst = PACK ? run : plain;
+    if (left >= kTileOps) {  // a whole tile (uniform branch): unconditional loads, all in flight before the first store
+        u4v v[kChunks];
+#pragma unroll
+        for (int k = 0; k < kChunks; ++k) v[k] = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(src) + (part * kChunks + k) * 256 + threadIdx.x);
+#pragma unroll
+        for (int k = 0; k < kChunks; ++k) __builtin_nontemporal_store(v[k], reinterpret_cast<u4v *>(dst) + (part * kChunks + k) * 256 + threadIdx.x);
+        return;
+    }
+    // the last, partial tile: what lies behind its ops is neither read nor written
+    if (part == 0)
+        for (uint32_t i = threadIdx.x; i < (uint32_t)left; i += 256u) dst[i] = src[i];
+}
+
+// The same for arrays that are not 16-byte aligned: one lane per op, word by word.
 __global__ __launch_bounds__(256) void k_tile_pack(TileList l, int count, uint64_t n, uint32_t *__restrict__ tiled) {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
@@ -839,6 +877,302 @@ __global__ __launch_bounds__(256, (PASSES * EPL <= 16) ? 7 : 4) void k_vec_chain
     }
 }
 
+// ---- the pipelined shape ---------------------------------------------------------------------------------------
+// The chained shape as a persistent workgroup whose waves have different jobs, so that its phases overlap instead of
+// following each other.  A one-tile workgroup is strictly phase-ordered -- loads, tree sums, walk, store -- and only other
+// resident workgroups keep the memory pipeline busy during its walk, which is why the one-tile shapes of the angular beat
+// want every wave they can get while their loads would prefer three or four workgroups per CU.  Here
+//   waves 0..2 ("loaders")  hold the operand loads of tile t + 2 in flight, and turn tile t + 1 (loaded one round earlier)
+//                           into per-beat tree sums in one of two LDS buffers;
+//   wave 3     ("walker")   meanwhile accumulates tile t out of the other buffer -- pair starts compacted with ballots, one
+//                           lane per vector pair, the lane of beat 0 continuing the pair that runs in from the previous
+//                           tile -- and stores its results.
+// One workgroup barrier per tile swaps the buffers.  The walker issues no operand loads, so its polls for the predecessor's
+// hand-over never wait behind a prefetch (in an earlier form, where all four waves prefetched and then walked, the first
+// poll of a wave drained its outstanding loads first and nothing overlapped: 0.64 of the HBM roof).
+//
+// Workgroup g of G takes tiles g, g + G, g + 2 G, ...; G is at most what the device keeps resident at once (launcher), so
+// every workgroup is running when another one waits for its hand-over: tile t - 1 belongs to workgroup g - 1 (or G - 1, one
+// round earlier), which publishes after the walk of its tile's last pair -- a walk that waits for nobody unless that one
+// pair spans the whole tile.  (A ticket counter that hands tiles out in order would make this independent of residency,
+// but one device-scope atomic per tile on a single word runs at about 20 M per second across the XCDs: 1.7 ms for the
+// 32768 tiles of 2^24 angular beats, ten times the kernel.)  Hand-over words, epoch, give-up count, the bounded wait
+// with its host-side repair, and the arithmetic are those of k_vec_chain, so the results are the same bits.
+
+// Tree sums of one beat part held by this lane: a / b = four elements, mbits = their mask bits (:221-245, :399-419 and the
+// adder tree :632-649, :783-803, :915-935, :1007-1027; angular :246-268, :420-453, :650-676, :804-832, :936-964).
+template <bool EUC> __device__ __forceinline__ void beat_tree(const f4v &a, const f4v &b, uint32_t mbits, float &r0, float &r1) {
+    float s0[4], s1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool on = (mbits >> j) & 1u;
+        if (EUC) {
+            const float d = on ? (a[j] - b[j]) : 0.0f;
+            s0[j] = d * d;
+        } else {
+            const float q = on ? a[j] : 0.0f;
+            const float c = on ? b[j] : 0.0f;
+            s0[j] = q * c;
+            s1[j] = c * c;
+        }
+    }
+    r1 = 0.0f;
+    if (EUC) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s0[j] = s0[j] + quad_xor2(s0[j]);  // i, i+8
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s0[j] = s0[j] + quad_xor1(s0[j]);  // i, i+4
+        r0 = (s0[0] + s0[2]) + (s0[1] + s0[3]);                        // i, i+2 then 0, 1
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s0[j] = s0[j] + quad_xor1(s0[j]); s1[j] = s1[j] + quad_xor1(s1[j]); }  // i, i+4
+        r0 = (s0[0] + s0[2]) + (s0[1] + s0[3]);
+        r1 = (s1[0] + s1[2]) + (s1[1] + s1[3]);
+    }
+}
+
+constexpr int kPipeLoadWaves = 3;  // of the workgroup's four
+
+// Orders this wave's LDS accesses: what its lanes wrote before is what its lanes read afterwards (no workgroup barrier needed
+// inside one wave, whose LDS instructions execute in order).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool EUC, bool NT, int PASSES>
+__global__ __launch_bounds__(256, 4) void k_vec_pipe(VecArgs args, uint64_t n, uint32_t tiles) {
+    constexpr int kLook = 4;                          // beat sums fetched per LDS round trip by the sparse-reset walk
+    constexpr int ROW = EUC ? 16 : 8;                 // floats per beat and vector
+    constexpr int LPB = ROW / 4;                      // lanes per beat
+    constexpr int BPP = kPipeLoadWaves * 64 / LPB;    // beats per pass of the loader waves
+    constexpr int SUB = PASSES * BPP;                 // beats per tile
+
+    static_assert(SUB % 4 == 0 && kLook % 4 == 0, "16-byte rows");
+    __shared__ float s_sum0[2][SUB + kLook];
+    __shared__ float s_sum1[EUC ? 1 : 2][EUC ? 1 : SUB + kLook];
+    __shared__ __align__(16) uint32_t s_ctl[2][SUB + kLook];
+    __shared__ uint32_t s_before[2];                  // the control word in front of the tile in that buffer
+    __shared__ __align__(16) float s_out0[SUB + kLook];
+    __shared__ __align__(16) float s_out1[EUC ? 4 : SUB + kLook];
+    __shared__ uint16_t s_start[SUB];                 // the walker's list of pair starts
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool loader = tid < kPipeLoadWaves * 64;
+    const int part = tid % LPB;  // which four elements of the beat
+    unsigned long long *const header = args.chain_header;
+    unsigned long long *const slots = args.chain;  // two words per tile
+    const int spins = args.debug_skip ? kChainSpinsDebug : kChainSpins;
+    const uint32_t G = gridDim.x;
+    if (blockIdx.x >= tiles) return;
+    const bool wide = ((reinterpret_cast<uintptr_t>(args.out0) | (EUC ? 0u : reinterpret_cast<uintptr_t>(args.out1))) & 15u) == 0u;
+
+    f4v va[PASSES], vb[PASSES];
+    uint32_t vc[PASSES];
+    uint32_t before = 0x10000u;
+    auto count_of = [&](uint32_t t) -> int {
+        const uint64_t left = n - (uint64_t)t * SUB;
+        return (left < (uint64_t)SUB) ? (int)left : SUB;
+    };
+    auto load = [&](uint32_t t) {  // loaders
+        const uint64_t base = (uint64_t)t * SUB;
+        const int cnt = count_of(t);
+#pragma unroll
+        for (int u = 0; u < PASSES; ++u) {
+            const int bl = u * BPP + tid / LPB;
+            if (bl < cnt) {
+                const uint64_t e = (base + bl) * ROW + part * 4;
+                va[u] = ld<f4v, NT>(args.a + e);
+                vb[u] = ld<f4v, NT>(args.b + e);
+                vc[u] = args.ctl[base + bl];
+            } else {
+                va[u] = (f4v)(0.0f); vb[u] = (f4v)(0.0f); vc[u] = 0u;
+            }
+        }
+        before = (tid == 0 && base != 0) ? args.ctl[base - 1] : 0x10000u;
+    };
+    auto sums = [&](uint32_t t, int buf) {  // loaders: the registers hold tile t
+        const int cnt = count_of(t);
+#pragma unroll
+        for (int u = 0; u < PASSES; ++u) {
+            const int bl = u * BPP + tid / LPB;
+            float r0, r1;
+            beat_tree<EUC>(va[u], vb[u], vc[u] >> (part * 4), r0, r1);
+            if (part == 0 && bl < cnt) {
+                s_sum0[buf][bl] = r0;
+                if (!EUC) s_sum1[buf][bl] = r1;
+                s_ctl[buf][bl] = vc[u];
+            }
+        }
+        if (tid == 0) s_before[buf] = before;
+    };
+
+    // prologue: the first tile's sums into buffer 0, the second tile's loads in flight
+    uint32_t tile = blockIdx.x;
+    if (loader) {
+        load(tile);
+        sums(tile, 0);
+        if (tile + G < tiles) load(tile + G);
+    }
+    __syncthreads();
+
+    int p = 0;
+    for (;; tile += G, p ^= 1) {
+        const uint32_t next = tile + G;  // (tiles < 2^31 and the grid is small: no wrap)
+        if (loader) {
+            if (next < tiles) {
+                sums(next, p ^ 1);
+                if (next + G < tiles) load(next + G);  // in flight for two rounds of the walker
+            }
+        } else {
+            const uint64_t base = (uint64_t)tile * SUB;
+            const int cnt = count_of(tile);
+            const bool last_tile = (tile + 1u == tiles);
+            const float *sum0 = s_sum0[p], *sum1 = s_sum1[EUC ? 0 : p];
+            const uint32_t *ctl = s_ctl[p];
+            // Does a pair run into this tile?  Then its running sums come from the previous tile's walker: ask for them now,
+            // look at the answer after the other pairs have been walked (a round trip to memory under full load takes
+            // longer than those walks).
+            const bool entering = lane == 0 && tile != 0u && (((s_before[p] >> 16) & 1u) == 0u);
+            unsigned long long *const from = slots + 2 * (uint64_t)(tile - (tile ? 1u : 0u));
+            unsigned long long got0 = 0ull, got1 = 0ull;
+            if (entering) {
+                got0 = __hip_atomic_load(from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!EUC) got1 = __hip_atomic_load(from + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // the pair starts of the tile (any order: every pair is walked by a lane of its own); a lane looks at four positions
+            int n_starts = 0;
+            for (int q0 = 0; 4 * q0 < cnt; q0 += 64) {
+                const int t = 4 * (q0 + lane);
+                const bool in = t < cnt;
+                const u4v c = in ? *reinterpret_cast<const u4v *>(ctl + t) : u4v{0u, 0u, 0u, 0u};
+                const uint32_t prev = (in && t != 0) ? ctl[t - 1] : 0u;
+                const bool st[4] = {((prev >> 16) & 1u) != 0u, t + 1 < cnt && ((c.x >> 16) & 1u) != 0u, t + 2 < cnt && ((c.y >> 16) & 1u) != 0u,
+                                    t + 3 < cnt && ((c.z >> 16) & 1u) != 0u};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned long long m = __ballot(st[j]);
+                    if (st[j]) s_start[n_starts + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(t + j);
+                    n_starts += __popcll(m);
+                }
+            }
+            // this wave's walk is the critical path of the round, so every pair is walked in the form that fetches four
+            // beat sums per LDS round trip (the padded arrays keep the look-ahead in bounds)
+            constexpr bool sparse = true;
+            wave_lds_fence();
+
+            auto hand_on = [&](float acc0, float acc1) {
+                if (last_tile) {
+                    args.state_out[0] = canon_nan(acc0);
+                    if (!EUC) args.state_out[1] = canon_nan(acc1);
+                } else if (args.debug_skip == 0u || tile + 1u != args.debug_skip) {
+                    __hip_atomic_store(slots + 2 * (uint64_t)tile, chain_word(args.epoch, acc0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!EUC) __hip_atomic_store(slots + 2 * (uint64_t)tile + 1, chain_word(args.epoch, acc1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            };
+            auto walk = [&](int i, float acc0, float acc1) {
+                if (!sparse) {
+                    bool rs;
+                    do {
+                        acc0 = acc0 + sum0[i];
+                        s_out0[i] = acc0;
+                        rs = ((ctl[i] >> 16) & 1u) != 0u;
+                        if (!EUC) {
+                            acc1 = acc1 + sum1[i];
+                            s_out1[i] = acc1;
+                        }
+                        ++i;
+                    } while (i < cnt && !rs);
+                    if (i == cnt) hand_on(rs ? 0.0f : acc0, rs ? 0.0f : acc1);
+                } else {
+                    bool more = true;
+                    while (more) {
+                        float v0[kLook], v1[kLook];
+                        uint32_t c[kLook];
+#pragma unroll
+                        for (int k = 0; k < kLook; ++k) {
+                            v0[k] = sum0[i + k];
+                            if (!EUC) v1[k] = sum1[i + k];
+                            c[k] = ctl[i + k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < kLook; ++k) {
+                            if (more) {
+                                const bool rs = ((c[k] >> 16) & 1u) != 0u;
+                                acc0 = acc0 + v0[k];
+                                s_out0[i + k] = acc0;
+                                if (!EUC) {
+                                    acc1 = acc1 + v1[k];
+                                    s_out1[i + k] = acc1;
+                                }
+                                const bool last = (i + k + 1 == cnt);
+                                if (last) hand_on(rs ? 0.0f : acc0, rs ? 0.0f : acc1);
+                                more = !rs && !last;
+                            }
+                        }
+                        i += kLook;
+                    }
+                }
+            };
+            for (int j = lane; j < n_starts; j += 64) walk((int)s_start[j], 0.0f, 0.0f);
+            if (lane == 0) {  // beat 0 of the tile: the stream's first beat, a fresh pair, or the pair that runs on from the previous tile
+                float acc0 = 0.0f, acc1 = 0.0f;
+                if (tile == 0u) {
+                    acc0 = args.state_in[0];
+                    if (!EUC) acc1 = args.state_in[1];
+                } else if (entering) {
+                    int spin = 0;
+                    while ((uint32_t)(got0 >> 32) != args.epoch || (!EUC && (uint32_t)(got1 >> 32) != args.epoch)) {
+                        if (++spin > spins) {  // bounded: counted, repaired by the host (api.cpp)
+                            atomicAdd(header, 1ull);
+                            got0 = got1 = 0ull;  // float bits of +0
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(4);
+                        got0 = __hip_atomic_load(from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!EUC) got1 = __hip_atomic_load(from + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    acc0 = __uint_as_float((uint32_t)got0);
+                    if (!EUC) acc1 = __uint_as_float((uint32_t)got1);
+                }
+                walk(0, acc0, acc1);
+            }
+            wave_lds_fence();
+            // coalesced result store, 16 bytes per lane where the arrays allow it
+            if (wide) {
+                for (int q0 = 0; 4 * q0 < cnt; q0 += 64) {
+                    const int t = 4 * (q0 + lane);
+                    if (t + 4 <= cnt) {
+                        f4v o0 = *reinterpret_cast<const f4v *>(s_out0 + t);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o0[j] = canon_nan(o0[j]);
+                        st<f4v, NT>(args.out0 + base + t, o0);
+                        if (!EUC) {
+                            f4v o1 = *reinterpret_cast<const f4v *>(s_out1 + t);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o1[j] = canon_nan(o1[j]);
+                            st<f4v, NT>(args.out1 + base + t, o1);
+                        }
+                    } else {
+                        for (int i = t; i < cnt; ++i) {
+                            st<float, NT>(args.out0 + base + i, canon_nan(s_out0[i]));
+                            if (!EUC) st<float, NT>(args.out1 + base + i, canon_nan(s_out1[i]));
+                        }
+                    }
+                }
+            } else {
+                for (int t0 = lane; t0 < cnt; t0 += 64) {
+                    st<float, NT>(args.out0 + base + t0, canon_nan(s_out0[t0]));
+                    if (!EUC) st<float, NT>(args.out1 + base + t0, canon_nan(s_out1[t0]));
+                }
+            }
+            wave_lds_fence();  // s_out and s_start are re-used in the next round
+        }
+        if (next >= tiles) break;
+        __syncthreads();  // buffer p ^ 1 holds the next tile's sums; buffer p is free for the one after it
+    }
+}
+
 size_t vec_chain_bytes(uint64_t n) { return 256 + ((n + 127) / 128) * 16; }  // (256 bytes of slack behind the last tile)
 
 // ------------------------------------------------------- ray pre-processing
@@ -1068,17 +1402,33 @@ hipError_t launch_tri_tiled(const float *in, uint32_t *out, uint64_t n, const Tu
     return hipGetLastError();
 }
 
+static bool tile_copy_aligned(const TileList &arrays, int count, const void *tiled) {
+    uintptr_t acc = reinterpret_cast<uintptr_t>(tiled);
+    for (int k = 0; k < count; ++k) acc |= reinterpret_cast<uintptr_t>(arrays.a[k]);
+    return (acc & 15u) == 0;
+}
+
 hipError_t launch_tile_pack(const TileList &arrays, int count, uint64_t n, uint32_t *tiled, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     if (count < 1 || count > kTileMaxArrays || !grid_fits(n)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_tile_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, arrays, count, n, tiled);
+    const uint64_t runs = ((n + kTileOps - 1) / kTileOps) * (uint64_t)count;
+    if (tile_copy_aligned(arrays, count, tiled) && runs * kCopySplit <= 0x7FFFFFFFull)
+        hipLaunchKernelGGL((k_tile_copy16<true>), dim3((unsigned)(runs * kCopySplit)), dim3(256),
+                           residency_lds(reinterpret_cast<const void *>(&k_tile_copy16<true>), 0, kCopyWgsPerCu), stream, arrays, (uint32_t)count, n, tiled);
+    else
+        hipLaunchKernelGGL(k_tile_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, arrays, count, n, tiled);
     return hipGetLastError();
 }
 
 hipError_t launch_tile_unpack(const uint32_t *tiled, int count, uint64_t n, const TileList &arrays, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     if (count < 1 || count > kTileMaxArrays || !grid_fits(n)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_tile_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tiled, count, n, arrays);
+    const uint64_t runs = ((n + kTileOps - 1) / kTileOps) * (uint64_t)count;
+    if (tile_copy_aligned(arrays, count, tiled) && runs * kCopySplit <= 0x7FFFFFFFull)
+        hipLaunchKernelGGL((k_tile_copy16<false>), dim3((unsigned)(runs * kCopySplit)), dim3(256),
+                           residency_lds(reinterpret_cast<const void *>(&k_tile_copy16<false>), 0, kCopyWgsPerCu), stream, arrays, (uint32_t)count, n, const_cast<uint32_t *>(tiled));
+    else
+        hipLaunchKernelGGL(k_tile_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tiled, count, n, arrays);
     return hipGetLastError();
 }
 
@@ -1123,47 +1473,115 @@ template <bool EUC, bool NT> static void launch_chain_p(const VecArgs &args, uin
     }
 }
 
-template <bool EUC> static hipError_t launch_vec(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream) {
-    if (n == 0) return hipSuccess;
+static int cu_count() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+        (void)hipGetLastError();
+        return 256;
+    }
+    return cus;
+}
+
+// The pipelined shape is a persistent grid: as many workgroups as stay resident together (residency x CUs), fewer when
+// the segment has fewer tiles; the residency cap is applied like everywhere else, through dynamic LDS.
+template <bool EUC, bool NT> static void launch_pipe_p(const VecArgs &args, uint64_t n, uint32_t tiles, int passes, int wgs, int dflt, hipStream_t stream) {
+    int w = (wgs > 0 && wgs <= 16) ? wgs : dflt;
+    if (w < 3) w = 3;
+    const uint64_t resident = (uint64_t)w * (uint64_t)cu_count();
+    const unsigned blocks = (unsigned)(tiles < resident ? tiles : resident);
+    switch (passes) {
+    case 2: RTDP_LAUNCH_VEC((k_vec_pipe<EUC, NT, 2>), blocks, w, w, stream, args, n, tiles); break;
+    case 8: RTDP_LAUNCH_VEC((k_vec_pipe<EUC, NT, 8>), blocks, w, w, stream, args, n, tiles); break;
+    default: RTDP_LAUNCH_VEC((k_vec_pipe<EUC, NT, 4>), blocks, w, w, stream, args, n, tiles); break;
+    }
+}
+
+// Which beat kernel a segment of n beats gets under tuning t (chain_ok: a hand-over workspace is available, i.e. the
+// launch is not being captured into a graph).  One place decides, the launcher and kernel_name_* both read it.
+struct VecShape { bool chained; bool pipe; int passes; uint32_t tile; int walk; int dflt_wgs; uint32_t diag; };
+
+template <bool EUC> static VecShape vec_shape(uint64_t n, const Tuning &t, bool chain_ok) {
     // Two shapes with identical results.  Chained: fixed tiles that hand their running sums on (needs the workspace).
     // Owning: a workgroup owns whole vector pairs and searches for their boundaries.  Measured inside the benchmark
-    // process (scripts/bench_ctx.sh, 2^24 beats): Euclidean 0.814 chained against 0.800 owning, angular 0.745 chained
-    // against 0.762 owning, so each opcode defaults to its better shape.  Variant 23 (21, 22): owning for both; 27
-    // (24, 25): chained for both.
+    // process (2^24 beats): Euclidean 0.814 chained against 0.800 owning, angular 0.745 chained against 0.762 owning,
+    // so each opcode defaults to its better shape.  Variant 23 (21, 22): owning for both; 27 (24, 25): chained for both.
     // Short angular segments (the quarters of a mixed batch, the segments behind the opcode partition of a record stream) are
     // the exception: up to 2^23 beats the chained shape leads on every box measured (2^22 beats: 0.66 against 0.64 of the HBM
-    // peak, 2^20: 0.52 against 0.49; scripts/beat_shapes.sh, scripts/ang_shape_check.sh), above that the two trade places by
-    // less than the box-to-box spread.
+    // peak, 2^20: 0.52 against 0.49), above that the two trade places by less than the box-to-box spread.
+    VecShape sh{};
     const bool short_angular = !EUC && n <= (1ull << 23);
-    const bool chained = args.chain != nullptr && (t.variant == 27 || t.variant == 24 || t.variant == 25 || ((EUC || short_angular) && !(t.variant >= 21 && t.variant <= 23)));
-    if (chained) {
-        VecArgs a2 = args;
-        a2.diag = (t.variant == 24) ? 1u : (t.variant == 25) ? 2u : 0u;
+    sh.chained = chain_ok && (t.variant == 27 || t.variant == 24 || t.variant == 25 || ((EUC || short_angular) && !(t.variant >= 21 && t.variant <= 23)));
+    const bool asked = (t.vec_passes == 2 || t.vec_passes == 4 || t.vec_passes == 8);
+    if (chain_ok && t.variant == 28) {  // the pipelined persistent shape (same workspace as the chained one); measured slower, never a default
+        sh.chained = sh.pipe = true;
+        sh.passes = asked ? t.vec_passes : (EUC ? 8 : 4);
+        if (EUC && sh.passes < 4) sh.passes = 4;
+        sh.dflt_wgs = 4;
+        return sh;
+    }
+    if (sh.chained) {
+        sh.diag = (t.variant == 24) ? 1u : (t.variant == 25) ? 2u : 0u;
         // Euclidean: eight load pairs per lane on long segments; on short ones twice as many, half as long workgroups fill the
-        // chip better (scripts/euclid_passes.sh, 4 against 8: 2^18 beats 0.44 / 0.40 of the HBM peak, 2^20 0.66 / 0.62, 2^22 equal,
-        // 2^24 0.81 / 0.83)
-        const int passes = (t.vec_passes == 2 || t.vec_passes == 4 || t.vec_passes == 8) ? t.vec_passes : (EUC ? (n <= (1ull << 21) ? 4 : 8) : 4);
-        if ((n + 127) / 128 > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        // chip better (4 against 8: 2^18 beats 0.44 / 0.40 of the HBM peak, 2^20 0.66 / 0.62, 2^22 equal, 2^24 0.81 / 0.83)
+        sh.passes = asked ? t.vec_passes : (EUC ? (n <= (1ull << 21) ? 4 : 8) : 4);
         // residency: the Euclidean shape (64 KiB of loads in flight per workgroup) is best with 4 workgroups per CU (0.824
         // of the HBM roof against 0.79 with the 6 its registers allow), the angular shape with all it can get
-        const int dflt = (EUC && passes == 8) ? kEucWgsPerCu : kVecWgsPerCu;
-        if (use_nt(t)) launch_chain_p<EUC, true>(a2, n, passes, t.wgs_per_cu, dflt, stream);
-        else launch_chain_p<EUC, false>(a2, n, passes, t.wgs_per_cu, dflt, stream);
-        return hipGetLastError();
+        sh.dflt_wgs = (EUC && sh.passes == 8) ? kEucWgsPerCu : kVecWgsPerCu;
+        return sh;
     }
     // defaults from interleaved sweeps on MI355X: sub-tiles of 512 beats for both opcodes; the Euclidean shape (loads
     // issued from the nominal start) wants the nominal tile equal to the sub-tile, the angular shape (loads from the
     // first pair boundary) a tile a few beats shorter, so that the pair that hangs over the nominal end still fits
     // the one sub-tile (504: 0.749 of the HBM roof against 0.738 with 512)
-    const int passes = (t.vec_passes == 2 || t.vec_passes == 4 || t.vec_passes == 8) ? t.vec_passes : (EUC ? 8 : 4);
-    uint32_t tile = t.vec_tile > 0 ? (uint32_t)t.vec_tile : (EUC ? 512u : 504u);
-    if (tile < 64u) tile = 64u;
-    const uint64_t blocks = (n + tile - 1) / tile;
+    sh.passes = asked ? t.vec_passes : (EUC ? 8 : 4);
+    sh.tile = t.vec_tile > 0 ? (uint32_t)t.vec_tile : (EUC ? 512u : 504u);
+    if (sh.tile < 64u) sh.tile = 64u;
+    sh.walk = (t.variant == 21) ? 1 : (t.variant == 22) ? 2 : 0;  // A/B only: 21 plain walk everywhere, 22 look-ahead walk everywhere
+    sh.dflt_wgs = kVecWgsPerCu;
+    return sh;
+}
+
+template <bool EUC> static hipError_t launch_vec(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const VecShape sh = vec_shape<EUC>(n, t, args.chain != nullptr);
+    if (sh.pipe) {
+        const uint64_t sub = (uint64_t)sh.passes * (kPipeLoadWaves * 64 / (EUC ? 4 : 2));  // >= 128 beats: the hand-over words are sized for that
+        const uint64_t tiles = (n + sub - 1) / sub;
+        if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        if (use_nt(t)) launch_pipe_p<EUC, true>(args, n, (uint32_t)tiles, sh.passes, t.wgs_per_cu, sh.dflt_wgs, stream);
+        else launch_pipe_p<EUC, false>(args, n, (uint32_t)tiles, sh.passes, t.wgs_per_cu, sh.dflt_wgs, stream);
+        return hipGetLastError();
+    }
+    if (sh.chained) {
+        VecArgs a2 = args;
+        a2.diag = sh.diag;
+        if ((n + 127) / 128 > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        if (use_nt(t)) launch_chain_p<EUC, true>(a2, n, sh.passes, t.wgs_per_cu, sh.dflt_wgs, stream);
+        else launch_chain_p<EUC, false>(a2, n, sh.passes, t.wgs_per_cu, sh.dflt_wgs, stream);
+        return hipGetLastError();
+    }
+    const uint64_t blocks = (n + sh.tile - 1) / sh.tile;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const int walk = (t.variant == 21) ? 1 : (t.variant == 22) ? 2 : 0;  // A/B only: 21 plain walk everywhere, 22 look-ahead walk everywhere
-    if (use_nt(t)) launch_vec_p<EUC, true>(args, n, tile, passes, walk, (unsigned)blocks, t.wgs_per_cu, kVecWgsPerCu, stream);
-    else launch_vec_p<EUC, false>(args, n, tile, passes, walk, (unsigned)blocks, t.wgs_per_cu, kVecWgsPerCu, stream);
+    if (use_nt(t)) launch_vec_p<EUC, true>(args, n, sh.tile, sh.passes, sh.walk, (unsigned)blocks, t.wgs_per_cu, sh.dflt_wgs, stream);
+    else launch_vec_p<EUC, false>(args, n, sh.tile, sh.passes, sh.walk, (unsigned)blocks, t.wgs_per_cu, sh.dflt_wgs, stream);
     return hipGetLastError();
+}
+
+// The kernels behind a launch, named as a profiler prints them (rocprofv3 --kernel-trace): what a committed counter pass
+// is keyed by, so a harness can tell whether the pass still describes the kernel the library picks.
+static const char *tf(bool b) { return b ? "true" : "false"; }
+
+void kernel_name_vec(bool euclid, uint64_t n, const Tuning &t, bool chain_ok, char *buf, size_t len) {
+    const VecShape sh = euclid ? vec_shape<true>(n, t, chain_ok) : vec_shape<false>(n, t, chain_ok);
+    if (sh.pipe) snprintf(buf, len, "rtdp::k_vec_pipe<%s, %s, %d>", tf(euclid), tf(use_nt(t)), sh.passes);
+    else if (sh.chained) snprintf(buf, len, "rtdp::k_vec_chain<%s, %s, %d, 4>", tf(euclid), tf(use_nt(t)), sh.passes);
+    else snprintf(buf, len, "rtdp::k_vec<%s, %s, %d>", tf(euclid), tf(use_nt(t)), sh.passes);
+}
+
+void kernel_name_ops(bool box, bool tiled, bool derive, int ops_per_lane_possible, const Tuning &t, char *buf, size_t len) {
+    if (tiled) { snprintf(buf, len, "rtdp::k_%s_tiled<%s, %s>", box ? "box" : "tri", tf(use_nt(t)), tf(derive)); return; }
+    if (box && t.variant == 10 && !derive) { snprintf(buf, len, "rtdp::k_box_pattern<2>"); return; }
+    snprintf(buf, len, "rtdp::k_%s%s<%d, %s>", box ? "box" : "tri", derive ? "_derive" : "", pick_v(t.ops_per_lane, ops_per_lane_possible * 4, 1), tf(use_nt(t)));
 }
 
 hipError_t launch_euclid(const VecArgs &args, uint64_t n, const Tuning &t, hipStream_t stream) { return launch_vec<true>(args, n, t, stream); }

@@ -39,6 +39,33 @@ def test_single_process_line():
     d = check_line(r.stdout, 1, 3, 1)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "ops/s" and "sample" in c
+    # the counter figures in the roofline block belong to the kernel the library really runs for this launch
+    r = d["roofline"]
+    assert r["kernels"] == {"box": "rtdp::k_box_tiled<true, false>"}
+    assert r["traffic"] is not None and "stale" not in r["traffic_source"]
+
+
+@pytest.mark.gpu
+def test_default_line_has_a_counter_pass_for_every_kernel_it_runs():
+    """profiles/traffic.json is looked up by the kernel name the library resolves (rt_dp_kernel_name): after a change of
+    kernel or of a default shape the committed passes must be regenerated, otherwise the line says "stale"."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = check_line(r.stdout, 1, 2, 1)
+    for name in ("box", "tri", "euclid", "angular", "mixed"):
+        rf = d["per_opcode"][name]["roofline"]
+        assert rf["traffic"] is not None and "stale" not in rf["traffic_source"], (name, rf)
+
+
+@pytest.mark.gpu
+def test_stale_counter_passes_are_called_stale():
+    """A kernel shape nobody measured (--vec-passes 2) must not inherit the figures of another kernel."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--log2-ops", "20", "--only", "euclid",
+                        "--vec-passes", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rf = check_line(r.stdout, 1, 2, 1)["roofline"]
+    assert rf["traffic"] is None and rf["traffic_source"].startswith("stale") and "k_vec_chain<true, true, 2, 4>" in rf["traffic_source"]
 
 
 @pytest.mark.gpu
@@ -55,7 +82,8 @@ def test_two_rank_rehearsal_line():
     d = check_line(r.stdout, 2, 3, 1)
     assert d["cpu_baseline"] is None
     assert set(d["per_opcode"]) == {"box", "tri", "euclid", "angular", "mixed", "box_plain", "tri_plain", "box_edge", "tri_edge",
-                                    "mixed_2p20", "mixed_2p20_plain", "knn"}
+                                    "pack_box", "pack_tri", "mixed_2p20", "mixed_2p20_plain", "knn"}
+    assert d["per_opcode"]["knn"]["exhaustive"]["exchange"] == "gloo (host staging)"     # the rehearsal never touches RCCL
     assert d["per_opcode"]["box"]["layout"] == "tiled" and d["per_opcode"]["box_plain"]["layout"] == "plain"
     assert d["per_opcode"]["euclid"]["layout"] == "plain"
     assert d["per_opcode"]["mixed_2p20"]["scaling"] == "strong" and d["per_opcode"]["knn"]["leaf_major"]["scaling"] == "strong"

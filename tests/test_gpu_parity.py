@@ -146,7 +146,7 @@ def test_angular_pairs(ctx, oracle, torch_cuda, pairs, device):
     check_angular(ctx, oracle, q, c, ctl, device, torch_cuda)
 
 
-@pytest.mark.parametrize("variant", [0, 23, 27, 21, 22])
+@pytest.mark.parametrize("variant", [0, 23, 27, 21, 22, 28])
 @pytest.mark.parametrize("tile,passes", [(64, 2), (240, 4), (256, 2), (512, 0), (512, 8), (2048, 4)])
 def test_vec_tiles_and_long_pairs(ctx, oracle, torch_cuda, tile, passes, variant):
     """Pairs longer than a sub-tile and longer than a whole tile; batch ends mid-pair;
@@ -175,7 +175,7 @@ def test_vec_no_reset_anywhere(ctx, oracle, torch_cuda):
 
 @pytest.mark.parametrize("width", [16, 8])
 @pytest.mark.parametrize("pair_beats", [1 << 22, 1 << 18])
-@pytest.mark.parametrize("variant", [23, 27])
+@pytest.mark.parametrize("variant", [23, 27, 28])
 def test_vec_reset_poor_streams_are_not_a_cliff(ctx, oracle, torch_cuda, width, pair_beats, variant):
     """2^22 beats with no reset at all (one endless pair) and with a reset every 2^18 beats: the workgroups whose
     nominal range holds no pair start must leave after looking at their own tile only (the accumulation itself is

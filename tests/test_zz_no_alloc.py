@@ -94,3 +94,53 @@ def test_static_compaction_empty_batch_and_limits(torch_cuda):
     ro.flags = flags.data_ptr()
     assert L.rt_dp_box_compact_static(ctx._h, C.byref(ro), 8, None, None, out.data_ptr(), out.data_ptr(), None, 8, None, None) == capi.ENULL
     ctx.close()
+
+
+def test_static_compaction_allocates_nothing(torch_cuda):
+    """The property the entry point exists for.  (1) Free device memory is the same before and after warmed-up calls.
+    (2) The call is captured into a HIP graph under the strictest capture mode torch offers (any hipMalloc, hipFree or
+    synchronisation on the capturing thread ends the capture with an error) and the replayed graph delivers the list of
+    the allocating entry point for whatever the result arrays hold by then."""
+    torch = torch_cuda
+    i32, f32 = torch.int32, torch.float32
+    ctx = capi.Context()
+    n = 20011
+    tmin, flags = _box_results(torch, ctx, n, 504)
+    cap = 4 * n
+    wi, wc, wt = torch.zeros(cap, dtype=i32, device="cuda"), torch.zeros(cap, dtype=i32, device="cuda"), torch.zeros(cap, dtype=f32, device="cuda")
+    want = ctx.box_compact(tmin, flags, wi, wc, wt)
+    gi, gc, gt = torch.zeros(cap, dtype=i32, device="cuda"), torch.zeros(cap, dtype=i32, device="cuda"), torch.zeros(cap, dtype=f32, device="cuda")
+    d_count = torch.full((1,), -1, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    ctx.box_compact_static(tmin, flags, gi, gc, d_count, gt, stream=stream.cuda_stream)     # warm-up: code objects are loaded
+    stream.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        ctx.box_compact_static(tmin, flags, gi, gc, d_count, gt, stream=stream.cuda_stream)
+    stream.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0, "device memory moved across rt_dp_box_compact_static calls"
+
+    gi.zero_(); gc.zero_(); gt.zero_(); d_count.fill_(-1)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+        ctx.box_compact_static(tmin, flags, gi, gc, d_count, gt, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(d_count.item()) == -1, "capture must not execute"
+    graph.replay()
+    torch.cuda.synchronize()
+    got = int(d_count.item())
+    assert got == want
+    assert torch.equal(gi[:got], wi[:got]) and torch.equal(gc[:got], wc[:got]) and torch.equal(gt[:got].view(i32), wt[:got].view(i32))
+    # new results in the same arrays, replay again: the graph holds no state of the first run
+    tmin2, flags2 = _box_results(torch, ctx, n, 505)
+    for dst, src in zip(tmin, tmin2):
+        dst.copy_(src)
+    flags.copy_(flags2)
+    want2 = ctx.box_compact(tmin, flags, wi, wc, wt)
+    graph.replay()
+    torch.cuda.synchronize()
+    got2 = int(d_count.item())
+    assert got2 == want2 and torch.equal(gi[:got2], wi[:got2]) and torch.equal(gc[:got2], wc[:got2])
+    ctx.close()
