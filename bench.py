@@ -105,7 +105,7 @@ def parse():
     p.add_argument("--trace-log2-rays", type=int, default=22)
     p.add_argument("--knn-tree", type=int, default=2, help="1: walk the k-d tree index with box pruning; 2: leaf-major search on the same index; 0: exhaustive scan")
     p.add_argument("--knn-walk", type=int, default=128, help="leaf-major search: leaves walked per query for the first bound")
-    p.add_argument("--knn-metric", default="euclid", help="euclid, or angular (exhaustive scan ranked by dot / sqrt(norm))")
+    p.add_argument("--knn-metric", default="euclid", help="euclid, or angular (ranked by dot / sqrt(norm); --knn-tree 0 exhaustive, 1 / 2 the tree walk with score bounds)")
     p.add_argument("--knn-data", default="uniform", help="uniform: U(-1,1)^16 (the named configuration); clustered: 256 Gaussian clusters, sigma 0.05")
     p.add_argument("--knn-leaf", type=int, default=128, help="points per tree leaf")
     p.add_argument("--knn-build", default="torch", help="torch: index built by torch sort / gather per level; device: rt_dp_knn_tree_build_device")
@@ -526,9 +526,10 @@ def knn_measure(a, ctx, world, rank, dev, tree_mode, steps, warmup):
     stream = bench_stream()
     times = []
     tree, build_ms = None, None
+    tree_stats = {}
     angular = a.knn_metric == "angular"
-    if angular:
-        tree_mode = 0
+    if angular and tree_mode == 2:
+        tree_mode = 1        # the leaf-major form exists for the Euclidean op only
     group = dist_util.data_group()   # RCCL if it works on every rank, else None: the exchange is staged through the host over gloo
     if tree_mode:
         from raytracer_amd import knn_tree
@@ -548,7 +549,9 @@ def knn_measure(a, ctx, world, rank, dev, tree_mode, steps, warmup):
             torch.cuda.synchronize()
             dist_util.barrier()
             t0 = time.perf_counter()
-            if tree is not None:
+            if tree is not None and angular:
+                d, i = knn.unpack_signed_keys(knn.all_gather_merge(knn_tree.local_topk_angular(ctx, tree, qry, splits=a.knn_splits or None, stats=tree_stats), group=group))
+            elif tree is not None:
                 d, i = knn_tree.search(ctx, tree, qry, group=group, splits=a.knn_splits or None, grouped=(tree_mode == 2), walk_leaves=a.knn_walk)
             elif angular:
                 d, i = knn.unpack_signed_keys(knn.all_gather_merge(knn.local_topk_angular(ctx, shard_pts, qry, lo, splits=a.knn_splits or None), group=group))
@@ -571,7 +574,7 @@ def knn_measure(a, ctx, world, rank, dev, tree_mode, steps, warmup):
             "workload": "knn: 2^%d points sharded over %d GPU(s), 2^%d queries replicated, dim 16, k 16, %s data, one all-gather merge" % (
                 a.knn_log2_points, world, a.knn_log2_queries, a.knn_data),
             "search": ("k-d tree %s, leaf %d, index build %.1f ms (not timed)" % ("leaf-major search" if tree_mode == 2 else "walk with box pruning", a.knn_leaf, build_ms)) if tree_mode else "exhaustive",
-            "pair_rate_equivalent_per_s": round(pairs / per, 1), "exchange": dist_util.data_backend(),
+            "pair_rate_equivalent_per_s": round(pairs / per, 1), "exchange": dist_util.data_backend(), **tree_stats,
             "valu": None if tree_mode else {"lane_ops_per_pair": lane_ops, "achieved_T_lane_ops": round(pairs * lane_ops / per / 1e12, 2), "peak_T_lane_ops": 78.6,
                                             "frac": round(pairs * lane_ops / per / 78.6e12, 4), "note": note}}
 
@@ -583,7 +586,8 @@ def run_knn(a, world, rank, local, dev):
         print(json.dumps({"metric": r["metric"], "value": r["value"], "unit": r["unit"], "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                           "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                           "data": "synthetic", "config": {"workload": r["workload"]}, "search": r["search"],
-                          "pair_rate_equivalent_per_s": r["pair_rate_equivalent_per_s"], "valu": r["valu"]}), flush=True)
+                          "pair_rate_equivalent_per_s": r["pair_rate_equivalent_per_s"], "valu": r["valu"], "exchange": r["exchange"],
+                          "leaves_scanned_fraction": r.get("leaves_scanned_fraction")}), flush=True)
     ctx.close()
     dist_util.shutdown()
 

@@ -232,7 +232,7 @@ int rt_dp_eval_ctx(rt_dp_ctx *ctx, const rt_dp_op_batch *in, rt_dp_result_batch 
  * capture); box / triangle batches carry no state and are not ordered.
  * The same holds for every entry point below that is described as
  * asynchronous (rt_dp_ray_prepare, rt_dp_knn_euclid16, rt_dp_knn_angular16,
- * rt_dp_knn_tree_euclid16); the synchronous ones wait for the whole device
+ * rt_dp_knn_tree_euclid16, rt_dp_knn_tree_angular16); the synchronous ones wait for the whole device
  * before they read their arguments.
  * `hip_stream` may be a stream under capture (hipStreamBeginCapture): the batch
  * then becomes kernel and 16-byte copy nodes of the caller's graph, nothing is
@@ -446,6 +446,18 @@ typedef struct rt_dp_knn_tree {
 
 int rt_dp_knn_tree_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, const float *queries, const uint32_t *home_leaf,
                             uint32_t n_queries, uint32_t splits, uint32_t *bound, float *out_dist, uint32_t *out_idx, void *hip_stream);
+
+/* The angular search (rt_dp_knn_angular16's lists, bit for bit) through the same tree.  A leaf is skipped only when an
+ * upper bound of every score that the datapath can compute for a point inside the leaf's box -- from the box's largest
+ * possible dot product with the query and its smallest (largest, for a negative dot) possible norm, widened for every
+ * rounding on the way -- stays below the 16th best score a query holds; leaves with unbounded boxes (NaN or infinite
+ * coordinates) are always scanned.  Arguments as for rt_dp_knn_tree_euclid16; out_neg_score / out_idx [splits][n_queries][16]
+ * as for rt_dp_knn_angular16.  d_leaves_scanned (device memory, 8-byte aligned, may be NULL) is incremented by the number
+ * of leaves scanned, summed over the waves of 64 consecutive queries: n_leaves x waves means nothing was pruned.  How
+ * much is pruned depends on the data: directions that cluster prune well, uniform directions in 16 dimensions hardly.
+ * Needs the extended datapath.  Asynchronous on `hip_stream` (NULL = context stream).  No counterpart in the reference.  */
+int rt_dp_knn_tree_angular16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, const float *queries, const uint32_t *home_leaf, uint32_t n_queries,
+                             uint32_t splits, uint32_t *bound, float *out_neg_score, uint32_t *out_idx, uint64_t *d_leaves_scanned, void *hip_stream);
 
 /* The leaf-major form of the same search, for data whose neighbouring queries do not share
  * their candidate leaves (e.g. uniform points in 16 dimensions, where the walk above prunes

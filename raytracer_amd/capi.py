@@ -135,7 +135,7 @@ class KnnTree(C.Structure):
 EXPORTS = ["rt_dp_create", "rt_dp_destroy", "rt_dp_eval", "rt_dp_eval_ctx", "rt_dp_launch", "rt_dp_synchronize", "rt_dp_tile_pack", "rt_dp_tile_unpack",
            "rt_dp_reset", "rt_dp_get_accum", "rt_dp_set_accum", "rt_dp_eval_bundles", "rt_dp_set_tuning", "rt_dp_set_option", "rt_dp_get_option", "rt_dp_knn_euclid16", "rt_dp_knn_angular16", "rt_dp_knn_tree_euclid16", "rt_dp_knn_tree_grouped_euclid16", "rt_dp_trace_closest", "rt_dp_box_compact", "rt_dp_box_compact_tiled", "rt_dp_box_compact_static", "rt_dp_beat_offsets_host", "rt_dp_pairs_to_beats", "rt_dp_beats_to_pairs", "rt_dp_bvh4_build_device", "rt_dp_knn_tree_build_device", "rt_dp_knn_home_leaf", "rt_dp_ray_prepare", "rt_dp_eval_bundles_device",
            "rt_dp_knn_tree_leaves", "rt_dp_knn_tree_build_host", "rt_dp_knn_home_leaf_host", "rt_dp_bvh4_max_nodes", "rt_dp_bvh4_build_host",
-           "rt_dp_shard_plan", "rt_dp_shard_plan_records", "rt_dp_kernel_name",
+           "rt_dp_shard_plan", "rt_dp_shard_plan_records", "rt_dp_kernel_name", "rt_dp_knn_tree_angular16",
            "rt_dp_last_error", "rt_dp_version", "rt_dp_device_count"]
 
 
@@ -183,6 +183,7 @@ def load():
     L.rt_dp_knn_euclid16.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.rt_dp_knn_angular16.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.rt_dp_knn_tree_euclid16.argtypes = [vp, C.POINTER(KnnTree), vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
+    L.rt_dp_knn_tree_angular16.argtypes = [vp, C.POINTER(KnnTree), vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]
     L.rt_dp_knn_tree_grouped_euclid16.argtypes = [vp, C.POINTER(KnnTree), vp, vp, C.c_uint32, C.c_uint32, vp, vp, C.POINTER(C.c_uint64 * 4)]
     L.rt_dp_bvh4_build_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.POINTER(C.c_uint32), vp, vp]
     L.rt_dp_beat_offsets_host.argtypes = [vp, C.c_uint64, C.c_uint32, vp]
@@ -494,6 +495,16 @@ class Context:
                      tree.leaf_lo.data_ptr(), tree.leaf_hi.data_ptr())
         _check(self._L.rt_dp_knn_tree_euclid16(self._h, C.byref(ct), queries.data_ptr(), home_leaf.data_ptr(), m, splits, bound.data_ptr(),
                                                out_dist.data_ptr(), out_idx.data_ptr(), C.c_void_p(stream) if stream else None))
+
+    def knn_tree_angular16(self, tree, queries, home_leaf, bound, out_neg_score, out_idx, splits=1, leaves_scanned=None, stream=None):
+        """rt_dp_knn_tree_angular16: tree is a raytracer_amd.knn_tree.KnnTree; out_* [splits, m, 16]; leaves_scanned: int64 CUDA tensor [1] or None."""
+        t = KnnTree(C.sizeof(KnnTree), tree.n_leaves, tree.leaf_size, 0, tree.points.data_ptr(), tree.index.data_ptr(), tree.leaf_lo.data_ptr(),
+                    tree.leaf_hi.data_ptr())
+        m = int(queries.shape[0])
+        assert out_neg_score.numel() == splits * m * 16 and out_idx.numel() == splits * m * 16 and bound.numel() >= m and home_leaf.numel() == m
+        _check(self._L.rt_dp_knn_tree_angular16(self._h, C.byref(t), queries.data_ptr(), home_leaf.data_ptr(), m, splits, bound.data_ptr(),
+                                                out_neg_score.data_ptr(), out_idx.data_ptr(), None if leaves_scanned is None else leaves_scanned.data_ptr(),
+                                                stream))
 
     def knn_tree_grouped_euclid16(self, tree, queries, home_leaf, out_dist, out_idx, walk_leaves=16):
         """Leaf-major exact top-16 (torch CUDA tensors): queries [m,16] sorted by home_leaf [m]; out_dist / out_idx [m,16].

@@ -1000,12 +1000,9 @@ static int bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt_dp_
     // carve the structure-of-arrays segments (operands and results) out of the staging buffer
     size_t total = 0;
     auto take = [&](size_t bytes) { size_t o = total; total += align_up(bytes ? bytes : 4); return o; };
-    size_t o_box[kBoxFields], o_boxt[4], o_boxf, o_tri[kTriFields], o_trik, o_trin, o_trid, o_trih;
-    for (auto &o : o_box) o = take(nb * 4);
-    for (auto &o : o_boxt) o = take(nb * 4);
-    o_boxf = take(nb * 4);
-    for (auto &o : o_tri) o = take(nt * 4);
-    o_trik = take(nt * 4); o_trin = take(nt * 4); o_trid = take(nt * 4); o_trih = take(nt * 4);
+    // box and triangle segments in tiled form: one buffer each way, which is what their kernels run fastest on
+    const size_t o_boxin = take((size_t)RT_DP_TILED_WORDS(nb, RT_DP_BOX_TILE_IN_WORDS) * 4), o_boxout = take((size_t)RT_DP_TILED_WORDS(nb, RT_DP_BOX_TILE_OUT_WORDS) * 4);
+    const size_t o_triin = take((size_t)RT_DP_TILED_WORDS(nt, RT_DP_TRI_TILE_IN_WORDS) * 4), o_triout = take((size_t)RT_DP_TILED_WORDS(nt, RT_DP_TRI_TILE_OUT_WORDS) * 4);
     const size_t o_ea = take(ne * 64), o_eb = take(ne * 64), o_ec = take(ne * 4), o_eo = take(ne * 4);
     const size_t o_aa = take(na * 32), o_ab = take(na * 32), o_ac = take(na * 4), o_ad = take(na * 4), o_an = take(na * 4);
     rc = grow(ctx->d_stage, ctx->stage_bytes, total);
@@ -1019,26 +1016,22 @@ static int bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt_dp_
     memset(&ob, 0, sizeof ob);
     memset(&rb, 0, sizeof rb);
     ob.struct_size = sizeof ob; rb.struct_size = sizeof rb;
-    ob.flags = RT_DP_F_DEVICE_PTRS;
+    ob.flags = RT_DP_F_DEVICE_PTRS | RT_DP_F_BOX_TILED | RT_DP_F_TRI_TILED;
     ob.n[0] = nt; ob.n[1] = nb; ob.n[2] = ne; ob.n[3] = na;
-    for (int a = 0; a < 3; ++a) { ob.box.org[a] = F(o_box[a]); ob.box.dir[a] = F(o_box[3 + a]); ob.box.inv[a] = F(o_box[6 + a]); }
-    ob.box.extent = F(o_box[9]);
-    for (int b = 0; b < 4; ++b)
-        for (int f = 0; f < 6; ++f) ob.box.aabb[b][f] = F(o_box[10 + 6 * b + f]);
-    for (int k = 0; k < 4; ++k) rb.box.tmin_out[k] = F(o_boxt[k]);
-    rb.box.flags = U(o_boxf);
-    for (int a = 0; a < 3; ++a) { ob.tri.org[a] = F(o_tri[a]); ob.tri.shear[a] = F(o_tri[3 + a]); }
-    for (int v = 0; v < 3; ++v)
-        for (int a = 0; a < 3; ++a) ob.tri.vtx[v][a] = F(o_tri[6 + 3 * v + a]);
-    ob.tri.k = U(o_trik);
-    rb.tri.t_num = F(o_trin); rb.tri.t_denom = F(o_trid); rb.tri.hit = U(o_trih);
+    ob.box.org[0] = F(o_boxin); rb.box.tmin_out[0] = F(o_boxout);
+    ob.tri.org[0] = F(o_triin); rb.tri.t_num = F(o_triout);
     ob.euc.a = F(o_ea); ob.euc.b = F(o_eb); ob.euc.ctl = U(o_ec); rb.euc.accumulator = F(o_eo);
     ob.ang.a = F(o_aa); ob.ang.b = F(o_ab); ob.ang.ctl = U(o_ac); rb.ang.dot_product = F(o_ad); rb.ang.norm = F(o_an);
 
+    // what the partition and re-assembly kernels address: the run of every word in tile 0 (they add the tile's offset)
     BoxArgs ba;
     TriArgs ta;
-    fill_box(ba, ob.box, rb.box);
-    fill_tri(ta, ob.tri, rb.tri);
+    for (int f = 0; f < kBoxFields; ++f) ba.in[f] = F(o_boxin) + (size_t)f * kTileOps;
+    for (int k = 0; k < 4; ++k) ba.tmin[k] = F(o_boxout) + (size_t)k * kTileOps;
+    ba.flags = U(o_boxout) + (size_t)4 * kTileOps;
+    for (int f = 0; f < kTriFields; ++f) ta.in[f] = F(o_triin) + (size_t)f * kTileOps;
+    ta.k = U(o_triin) + (size_t)kTriFields * kTileOps;
+    ta.t_num = F(o_triout); ta.t_denom = F(o_triout) + (size_t)kTileOps; ta.hit = U(o_triout) + (size_t)2 * kTileOps;
     VecArgs ea{ob.euc.a, ob.euc.b, ob.euc.ctl, rb.euc.accumulator, nullptr, nullptr, nullptr};
     VecArgs aa{ob.ang.a, ob.ang.b, ob.ang.ctl, rb.ang.dot_product, rb.ang.norm, nullptr, nullptr};
     HIP_TRY(stream_scatter(in_words, n, blockcnt, slot, ba, ta, ea, aa, s));
@@ -1137,6 +1130,37 @@ int rt_dp_knn_tree_euclid16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, const fl
     if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
     HIP_TRY(launch_knn_tree16(tree->points, tree->index, tree->leaf_lo, tree->leaf_hi, nl, ls, queries, home_leaf, n_queries, log2_splits, 0, bound,
                               out_dist, out_idx, hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
+    return RT_DP_OK;
+}
+
+int rt_dp_knn_tree_angular16(rt_dp_ctx *ctx, const rt_dp_knn_tree *tree, const float *queries, const uint32_t *home_leaf, uint32_t n_queries,
+                             uint32_t splits, uint32_t *bound, float *out_neg_score, uint32_t *out_idx, uint64_t *d_leaves_scanned, void *hip_stream) {
+    if (!ctx || !tree) return fail(RT_DP_ENULL, "rt_dp_knn_tree_angular16: NULL argument");
+    if (tree->struct_size != sizeof(rt_dp_knn_tree)) return fail(RT_DP_EINVAL, "rt_dp_knn_tree.struct_size does not match this library");
+    if (!ctx->extended) return fail(RT_DP_EINVAL, "rt_dp_knn_tree_angular16: the baseline datapath has no angular op");
+    if (n_queries == 0) return RT_DP_OK;
+    if (!queries || !home_leaf || !bound || !out_neg_score || !out_idx || !tree->points || !tree->index || !tree->leaf_lo || !tree->leaf_hi)
+        return fail(RT_DP_ENULL, "rt_dp_knn_tree_angular16: NULL array");
+    const uint32_t nl = tree->n_leaves, ls = tree->leaf_size;
+    if (nl == 0 || (nl & (nl - 1))) return fail(RT_DP_EINVAL, "n_leaves = %u is not a power of two", nl);
+    if (ls == 0 || (ls & 3u)) return fail(RT_DP_EINVAL, "leaf_size = %u is not a positive multiple of 4", ls);
+    if ((uint64_t)nl * ls > 0xFFFFFFFFull) return fail(RT_DP_EINVAL, "n_leaves * leaf_size exceeds the 32-bit slot range");
+    if (splits == 0 || (splits & (splits - 1)) || splits > nl || splits > 65535u)
+        return fail(RT_DP_EINVAL, "splits = %u must be a power of two not above n_leaves", splits);
+    if ((reinterpret_cast<uintptr_t>(tree->points) | reinterpret_cast<uintptr_t>(queries)) & 7u)
+        return fail(RT_DP_EALIGN, "rt_dp_knn_tree_angular16: coordinate arrays must be 8-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(tree->index) | reinterpret_cast<uintptr_t>(tree->leaf_lo) | reinterpret_cast<uintptr_t>(tree->leaf_hi) |
+         reinterpret_cast<uintptr_t>(home_leaf) | reinterpret_cast<uintptr_t>(bound) | reinterpret_cast<uintptr_t>(out_neg_score) |
+         reinterpret_cast<uintptr_t>(out_idx)) & 3u)
+        return fail(RT_DP_EALIGN, "rt_dp_knn_tree_angular16: arrays must be 4-byte aligned");
+    if (reinterpret_cast<uintptr_t>(d_leaves_scanned) & 7u) return fail(RT_DP_EALIGN, "rt_dp_knn_tree_angular16: d_leaves_scanned must be 8-byte aligned");
+    uint32_t log2_splits = 0;
+    while ((1u << log2_splits) < splits) ++log2_splits;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RT_DP_EHIP, "cannot select device %d", ctx->device);
+    HIP_TRY(launch_knn_tree_ang16(tree->points, tree->index, tree->leaf_lo, tree->leaf_hi, nl, ls, queries, home_leaf, n_queries, log2_splits, bound,
+                                  out_neg_score, out_idx, reinterpret_cast<unsigned long long *>(d_leaves_scanned),
+                                  hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream));
     return RT_DP_OK;
 }
 

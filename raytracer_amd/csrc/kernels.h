@@ -163,6 +163,10 @@ hipError_t trace_finish(const unsigned long long *best, uint32_t n, float *out_t
 hipError_t launch_knn_tree16(const float *pts, const uint32_t *index, const float *leaf_lo, const float *leaf_hi, uint32_t n_leaves,
                              uint32_t leaf_size, const float *qry, const uint32_t *home, uint32_t n_qry, uint32_t log2_splits, uint32_t walk,
                              uint32_t *bound, float *out_d, uint32_t *out_i, hipStream_t stream);
+// the angular search through the same index; *scanned (or NULL) accumulates the leaves scanned, summed over waves of 64 queries
+hipError_t launch_knn_tree_ang16(const float *pts, const uint32_t *index, const float *leaf_lo, const float *leaf_hi, uint32_t n_leaves,
+                                 uint32_t leaf_size, const float *qry, const uint32_t *home, uint32_t n_qry, uint32_t log2_splits,
+                                 uint32_t *bound, float *out_d, uint32_t *out_i, unsigned long long *scanned, hipStream_t stream);
 struct KnnTreeView {
     const float *pts;
     const uint32_t *index;

@@ -336,6 +336,143 @@ hipError_t launch_knn_tree16(const float *pts, const uint32_t *index, const floa
     return hipGetLastError();
 }
 
+// ---- the angular search through the same tree ---------------------------------------------
+// Largest score = dot / sqrt(norm) first.  A leaf is skipped only when NO point inside its box can reach a lane's list:
+// with U an upper bound of every COMPUTED score in the box, the leaf is scanned unless -U > thr for every lane (thr = the
+// lane's 16th best negated score so far, or the one its splits share).  What is scanned goes through the exhaustive
+// kernel's code (norm once per point, the rsq filter, exact keys), so the lists are those of k_knn_euclid16<true>.
+//
+// U, per query q and box [lo, hi] (float arithmetic; its own rounding, at most 2^-20 relative on sums of 16 terms, is
+// covered by the margins):
+//   D  = sum_i max(q_i lo_i, q_i hi_i)   >= the exact dot product with any c in the box
+//   A  = sum_i max(|q_i lo_i|, |q_i hi_i|) >= sum_i |q_i c_i|: the datapath's dot (16 rounded products, adder trees and
+//        accumulator steps at most 6 additions deep, :420-453, :650-676 ... :1028-1064) differs from the exact one by less
+//        than 2^-21 A, plus at most 2^-140 for products that lose bits in the subnormal range
+//   m2 = sum_i min(c_i^2 : lo_i <= c_i <= hi_i),  M2 = sum_i max(lo_i^2, hi_i^2): the exact norm lies between them and the
+//        datapath's norm (non-negative terms) within 2^-21 relative and 2^-140 absolute of it
+//   the two correctly rounded operations of the consumer step (IOSpec.scala:21-23) add 2^-23 relative.
+//   num = D + 2^-17 A + 1e-36;   num >= 0:  U = num / sqrt(m2 (1 - 2^-17) - 1e-36) * (1 + 2^-17) + 1e-36   (+Inf when the
+//   root's argument is not positive: a norm that may underflow to 0 makes the score infinite);   num < 0:  U = num /
+//   sqrt(M2 (1 + 2^-17) + 1e-36) * (1 - 2^-17)   (the absolute terms also cover squares and products of the bound's own
+//   arithmetic that underflow, 16 x 2^-126 at most).
+// Where float overflow could break these relations (A or M2 beyond 1e37), where the box is unbounded in a dimension the
+// query uses (0 x Inf = NaN), or where a leaf holds NaN coordinates (box unbounded by the caller's contract), the bound
+// comes out +Inf or NaN and the test, written as a negated compare, scans the leaf.  An empty box (lo > hi: a leaf of pad
+// slots only) is skipped: its slots produce NaN scores, which no list takes.
+//
+// The splits of one query share thr through bound[q] as the order-preserving integer image of the float (negative:
+// all bits flipped, otherwise sign bit set), combined with an atomic min.
+__device__ __forceinline__ uint32_t ordered_bits(float v) {
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+
+__global__ __launch_bounds__(256) void k_knn_tree_ang16(KnnTreeArgs tree, const float *__restrict__ qry, const uint32_t *__restrict__ home,
+                                                       uint32_t n_qry, uint32_t *__restrict__ bound, float *__restrict__ out_d,
+                                                       uint32_t *__restrict__ out_i, unsigned long long *__restrict__ scanned) {
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool live = q < n_qry;
+    const uint32_t qq = live ? q : (n_qry - 1);
+    f2v qv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) qv[k] = reinterpret_cast<const f2v *>(qry)[(size_t)qq * 8 + k];
+
+    float bd[kTopK];
+    uint32_t bi[kTopK];
+#pragma unroll
+    for (int j = 0; j < kTopK; ++j) { bd[j] = __uint_as_float(0x7F800000u); bi[j] = 0xFFFFFFFFu; }
+    float pd = __uint_as_float(0x7FC00000u);
+    uint32_t pi = 0;
+    float thr = __uint_as_float(0x7F800000u);
+    float gate = knn_gate(thr);
+    float published = thr;
+
+    const uint32_t split = blockIdx.y;
+    const uint32_t per_split = tree.n_leaves >> tree.log2_splits;
+    const uint32_t hh = (__builtin_amdgcn_readfirstlane(home[qq]) >> tree.log2_splits) & (per_split - 1u);
+    const f2v *pts2 = reinterpret_cast<const f2v *>(tree.pts);
+    uint32_t n_scanned = 0;
+
+    for (uint32_t t = 0; t < per_split; ++t) {
+        const uint32_t leaf = ((hh ^ t) << tree.log2_splits) | split;  // wave-uniform
+        const float *lo = tree.leaf_lo + (size_t)leaf * 16, *hi = tree.leaf_hi + (size_t)leaf * 16;
+        const float shared = ordered_float(__hip_atomic_load(bound + qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (shared < thr) { thr = shared; gate = knn_gate(thr); }
+        float D = 0.0f, A = 0.0f, m2 = 0.0f, M2 = 0.0f;
+        bool empty = false;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float l = lo[i], h = hi[i], x = (i & 1) ? qv[i >> 1].y : qv[i >> 1].x;
+            empty |= l > h;
+            const float pl = x * l, ph = x * h;
+            D += fmaxf(pl, ph);
+            A += fmaxf(fabsf(pl), fabsf(ph));
+            const float ll = l * l, hq = h * h;
+            m2 += (l > 0.0f) ? ll : ((h < 0.0f) ? hq : 0.0f);
+            M2 += fmaxf(ll, hq);
+        }
+        constexpr float kEps = 7.62939453125e-06f, kAbs = 1.0e-36f;  // 2^-17
+        const float num = D + A * kEps + kAbs;
+        float U;
+        if (num >= 0.0f) {
+            const float den2 = m2 * (1.0f - kEps) - kAbs;
+            U = (den2 > 0.0f) ? num / sqrtf(den2) * (1.0f + kEps) + kAbs : __uint_as_float(0x7F800000u);
+        } else {
+            U = num / sqrtf(M2 * (1.0f + kEps) + kAbs) * (1.0f - kEps);
+        }
+        const bool safe = (A < 1.0e37f) && (M2 < 1.0e37f);  // false for NaN as well
+        const bool skip = empty || (safe && (-U > thr));
+        if (!__any(!skip)) continue;
+        ++n_scanned;
+
+        const uint32_t *ix = tree.index + (size_t)leaf * tree.leaf_size;
+        for (uint32_t jb = 0; jb < tree.leaf_size; jb += 64u) {
+            const uint32_t cnt = (tree.leaf_size - jb < 64u) ? (tree.leaf_size - jb) : 64u;  // a multiple of 4
+            // this lane's point of the block: its norm and the reciprocal square root estimate of the filter
+            const f2v *mine = pts2 + ((size_t)leaf * tree.leaf_size + jb + (lane < cnt ? lane : cnt - 1u)) * 8;
+            f2v c[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[k] = mine[k];
+            const float my_norm = knn_norm(c);
+            const float my_rsq = (my_norm < 1.0e-30f) ? __uint_as_float(0x7FC00000u) : __builtin_amdgcn_rsqf(my_norm);
+            for (uint32_t u = 0; u < cnt; u += kKnnUnroll) {
+                const f2v *p = pts2 + ((size_t)leaf * tree.leaf_size + jb + u) * 8;  // wave-uniform address
+                float dot[kKnnUnroll];
+#pragma unroll
+                for (int v = 0; v < kKnnUnroll; ++v) dot[v] = knn_dot(qv, p + v * 8);
+#pragma unroll
+                for (int v = 0; v < kKnnUnroll; ++v)
+                    knn_offer_angular(bd, bi, pd, pi, thr, gate, dot[v], lane_read(my_norm, u + v), lane_read(my_rsq, u + v), ix[jb + u + v]);
+            }
+        }
+        if (live && bd[kTopK - 1] < published) {
+            published = bd[kTopK - 1];
+            atomicMin(bound + q, ordered_bits(published));
+        }
+    }
+    knn_insert(bd, bi, pd, pi);
+    if (live) {
+        const size_t o = ((size_t)blockIdx.y * n_qry + q) * kTopK;
+#pragma unroll
+        for (int t = 0; t < kTopK; ++t) { out_d[o + t] = bd[t]; out_i[o + t] = bi[t]; }
+    }
+    if (scanned && lane == 0) atomicAdd(scanned, (unsigned long long)n_scanned);  // leaves scanned, summed over waves (statistics)
+}
+
+hipError_t launch_knn_tree_ang16(const float *pts, const uint32_t *index, const float *leaf_lo, const float *leaf_hi, uint32_t n_leaves,
+                                 uint32_t leaf_size, const float *qry, const uint32_t *home, uint32_t n_qry, uint32_t log2_splits,
+                                 uint32_t *bound, float *out_d, uint32_t *out_i, unsigned long long *scanned, hipStream_t stream) {
+    if (n_qry == 0) return hipSuccess;
+    hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(bound), 0xFF800000u, n_qry, stream);  // ordered image of +Inf: nothing known yet
+    if (e != hipSuccess) return e;
+    KnnTreeArgs tree{pts, index, leaf_lo, leaf_hi, n_leaves, leaf_size, log2_splits, 0u};
+    dim3 grid((n_qry + 255) / 256, 1u << log2_splits);
+    hipLaunchKernelGGL(k_knn_tree_ang16, grid, dim3(256), 0, stream, tree, qry, home, n_qry, bound, out_d, out_i, scanned);
+    return hipGetLastError();
+}
+
 // ---- leaf-major search ------------------------------------------------------------------
 // Where neighbouring queries do not share their candidate leaves (uniform data in 16
 // dimensions: a query needs ~27 % of the leaves, 64 neighbouring queries together 99 %),

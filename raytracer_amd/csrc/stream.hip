@@ -73,6 +73,12 @@ __global__ __launch_bounds__(1024) void k_stream_scan(uint32_t *__restrict__ blo
         }
 }
 
+// The box and triangle segments behind the partition are tiled segments (rt_dp.h: [tile][word][kTileOps]): pointer f is the
+// run of word f in tile 0, and op r of a segment with W words per op lives at offset tiled_at(r, W) from it.
+__device__ __forceinline__ uint64_t tiled_at(uint32_t r, uint32_t words) {
+    return (uint64_t)(r / kTileOps) * kTileOps * words + (r % kTileOps);
+}
+
 struct StreamSegs {  // writable images of the per-opcode operand arrays
     float *box[kBoxFields];
     float *tri[kTriFields];
@@ -105,18 +111,20 @@ __global__ __launch_bounds__(kBlk) void k_stream_scatter(const uint32_t *__restr
     slot[i] = op | (reset << 2) | (r << 3);
 
     if (op == 1u) {  // Quadbox: origin, dir, inv, extent, four AABBs
+        const uint64_t at = tiled_at(r, kBoxFields);
 #pragma unroll
-        for (int f = 0; f < 10; ++f) seg.box[f][r] = __uint_as_float(rec[1 + f]);
+        for (int f = 0; f < 10; ++f) seg.box[f][at] = __uint_as_float(rec[1 + f]);
 #pragma unroll
-        for (int f = 0; f < 24; ++f) seg.box[10 + f][r] = __uint_as_float(rec[17 + f]);
+        for (int f = 0; f < 24; ++f) seg.box[10 + f][at] = __uint_as_float(rec[17 + f]);
     } else if (op == 0u) {  // Triangle: origin, shear, vertices, selectors
+        const uint64_t at = tiled_at(r, kTriInWords);
 #pragma unroll
-        for (int f = 0; f < 3; ++f) seg.tri[f][r] = __uint_as_float(rec[1 + f]);
+        for (int f = 0; f < 3; ++f) seg.tri[f][at] = __uint_as_float(rec[1 + f]);
 #pragma unroll
-        for (int f = 0; f < 3; ++f) seg.tri[3 + f][r] = __uint_as_float(rec[14 + f]);
+        for (int f = 0; f < 3; ++f) seg.tri[3 + f][at] = __uint_as_float(rec[14 + f]);
 #pragma unroll
-        for (int f = 0; f < 9; ++f) seg.tri[6 + f][r] = __uint_as_float(rec[41 + f]);
-        seg.tri_k[r] = (rec[11] & 3u) | ((rec[12] & 3u) << 2) | ((rec[13] & 3u) << 4);
+        for (int f = 0; f < 9; ++f) seg.tri[6 + f][at] = __uint_as_float(rec[41 + f]);
+        seg.tri_k[at] = (rec[11] & 3u) | ((rec[12] & 3u) << 2) | ((rec[13] & 3u) << 4);
     } else if (op == 2u) {  // Euclidean beat
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -157,17 +165,19 @@ __global__ __launch_bounds__(kBlk) void k_stream_gather(const uint32_t *__restri
         w[0] = op;
         if (extended) { w[17] = reset; w[20] = reset; }
         if (op == 1u) {
-            const uint32_t fl = res.flags[r];
+            const uint64_t at = tiled_at(r, kBoxOutWords);
+            const uint32_t fl = res.flags[at];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                w[1 + k] = __float_as_uint(res.tmin[k][r]);
+                w[1 + k] = __float_as_uint(res.tmin[k][at]);
                 w[5 + k] = (fl >> k) & 1u;
                 w[9 + k] = (fl >> (4 + 2 * k)) & 3u;
             }
         } else if (op == 0u) {
-            w[13] = __float_as_uint(res.t_num[r]);
-            w[14] = __float_as_uint(res.t_denom[r]);
-            w[15] = res.hit[r];
+            const uint64_t at = tiled_at(r, kTriOutWords);
+            w[13] = __float_as_uint(res.t_num[at]);
+            w[14] = __float_as_uint(res.t_denom[at]);
+            w[15] = res.hit[at];
         } else if (op == 2u) {
             if (extended) w[16] = __float_as_uint(res.euc[r]);
         } else {

@@ -114,6 +114,35 @@ def local_topk(ctx, tree, queries, splits=None, k=knn.TOPK, stream=None):
     return out
 
 
+def local_topk_angular(ctx, tree, queries, splits=None, k=knn.TOPK, stream=None, stats=None):
+    """Top-k of every query by the angular op's score over the tree's points, as signed keys [m, k] of (minus score, index):
+    the same keys as knn.local_topk_angular on the same points (rt_dp_knn_tree_angular16 skips only leaves that provably
+    cannot contribute).  stats (a dict, or None) receives the share of (wave, leaf) pairs that were scanned."""
+    m = int(queries.shape[0])
+    home = tree.home_leaf(queries)
+    order = home.argsort(stable=True)
+    qs = queries[order].contiguous()
+    hs = home[order].contiguous()
+    splits = splits or default_splits(tree, m)
+    v = torch.empty(splits, m, knn.TOPK, dtype=torch.float32, device=queries.device)
+    i = torch.empty(splits, m, knn.TOPK, dtype=torch.int32, device=queries.device)
+    bound = torch.empty(m, dtype=torch.int32, device=queries.device)
+    scanned = torch.zeros(1, dtype=torch.int64, device=queries.device) if stats is not None else None
+    s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+    if s == 0:
+        torch.cuda.current_stream().synchronize()
+    ctx.knn_tree_angular16(tree, qs, hs, bound, v, i, splits=splits, leaves_scanned=scanned, stream=s)
+    if s == 0:
+        ctx.synchronize()
+    if stats is not None:
+        waves = ((m + 255) // 256) * 4
+        stats["leaves_scanned_fraction"] = float(scanned.item()) / float(waves * tree.n_leaves)
+    keys = knn.merge_keys(knn.pack_signed_keys(v, i), k)
+    out = torch.empty_like(keys)
+    out[order] = keys
+    return out
+
+
 def local_topk_grouped(ctx, tree, queries, k=knn.TOPK, walk_leaves=128, stats=None):
     """The same keys as local_topk through the leaf-major search (for data on which the wave walk cannot prune)."""
     m = int(queries.shape[0])

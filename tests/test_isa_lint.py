@@ -36,9 +36,9 @@ FUSED = re.compile(r"^v_(pk_)?(fma|fmac|mad|mac|madak|madmk|fmaak|fmamk)(_legacy
 MINMAX = re.compile(r"^v_(pk_)?(min3?|max3?|med3|minimum3?|maximum3?)(_legacy)?_" + FLOAT)
 
 # kernels that divide: fused ops allowed, but only the division / square-root expansions
-DIVIDES = re.compile(r"k_ray_prepare|k_box_derive|k_tri_derive|k_box_tiledILb[01]ELb1E|k_tri_tiledILb[01]ELb1E|k_trace_init|k_trace_tri|k_trace_dfs|k_knn_euclid16ILb1E|k_bvh_codes")
+DIVIDES = re.compile(r"k_ray_prepare|k_box_derive|k_tri_derive|k_box_tiledILb[01]ELb1E|k_tri_tiledILb[01]ELb1E|k_trace_init|k_trace_tri|k_trace_dfs|k_knn_euclid16ILb1E|k_knn_tree_ang16|k_bvh_codes")
 # bounds of search structures (not datapath ops): float min / max allowed
-BOUNDS = re.compile(r"k_knn_tree16|k_knn_pairs|k_bvh_bounds|k_bvh_codes|k_lbvh_boxes|k_kd_")
+BOUNDS = re.compile(r"k_knn_tree16|k_knn_tree_ang16|k_knn_pairs|k_bvh_bounds|k_bvh_codes|k_lbvh_boxes|k_kd_")
 # the kernels that evaluate datapath ops and must exist in the library (so a renamed kernel cannot dodge the check)
 MUST_SEE = ["5k_boxILi1ELb1E", "5k_triILi1ELb1E", "k_box_tiledILb1ELb0E", "k_tri_tiledILb1ELb0E", "5k_vecILb1ELb1E", "5k_vecILb0ELb1E", "k_stream_eval", "k_stream_fold", "k_stream_chainE",
             "k_knn_euclid16ILb0E", "k_trace_box", "k_trace_dfs"]

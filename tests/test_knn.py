@@ -152,6 +152,54 @@ def test_tree_search_equals_exhaustive_search(ctx, oracle, torch_cuda, cloud, n,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cloud,n,m,leaf,splits", [
+    ("uniform", 10, 5, 4, 1), ("uniform", 5000, 300, 64, 1), ("uniform", 5000, 300, 64, 4), ("uniform", 40000, 1000, 128, None),
+    ("clustered", 30000, 700, 32, 8), ("clustered", 30000, 700, 128, None), ("lowdim", 50000, 600, 64, None), ("scaled", 30000, 500, 64, None)])
+@pytest.mark.parametrize("build", ["torch", "device"])
+def test_angular_tree_search_equals_exhaustive_angular_search(ctx, oracle, torch_cuda, cloud, n, m, leaf, splits, build):
+    """rt_dp_knn_tree_angular16 skips leaves on a bound of the score; its lists must be those of the exhaustive angular kernel
+    (pinned to the oracle above), key for key: uniform data (zero-norm points, NaN and infinite coordinates, tiny norms, a
+    zero query, ties), clustered directions (where it really prunes), a low-dimensional subspace, and clusters scaled over
+    sixty orders of magnitude (norms and dot products near both ends of the float range)."""
+    torch = torch_cuda
+    from raytracer_amd import knn, knn_tree
+    if cloud == "uniform":
+        pts, qry = make_cloud(n, m, seed=n + m + leaf)
+        if n >= 64:
+            pts[30] = 0.0
+            pts[31] = pts[32] * f32(2.0)
+            pts[33] = pts[34]
+            pts[35] *= f32(1e-25)
+            qry[2] = 0.0
+    elif cloud == "clustered":
+        pts, qry = clustered_cloud(n, m, seed=leaf)
+    elif cloud == "lowdim":
+        rng = np.random.default_rng(9)
+        basis = rng.normal(0, 1, (3, 16))
+        pts = (rng.uniform(-1, 1, (n, 3)) @ basis).astype(f32)
+        qry = (rng.uniform(-1, 1, (m, 3)) @ basis).astype(f32)
+    else:
+        pts, qry = clustered_cloud(n, m, seed=77)
+        rng = np.random.default_rng(78)
+        pts = (pts * (f32(10.0) ** rng.integers(-30, 18, (n, 1)).astype(f32))).astype(f32)      # squares from the subnormal range up to 1e36
+        qry = (qry * (f32(10.0) ** rng.integers(-20, 18, (m, 1)).astype(f32))).astype(f32)
+    P, Q = torch.from_numpy(pts).cuda(), torch.from_numpy(qry).cuda()
+    want = knn.local_topk_angular(ctx, P, Q, 1000)
+    tree = knn_tree.KnnTree.build_device(ctx, P, leaf_size=leaf, index_base=1000) if build == "device" else knn_tree.KnnTree(P, leaf_size=leaf, index_base=1000)
+    stats = {}
+    got = knn_tree.local_topk_angular(ctx, tree, Q, splits=splits, stats=stats)
+    bad = (got != want).any(1).nonzero().flatten().tolist()
+    assert not bad, (stats, bad[:5])
+    assert 0.0 < stats["leaves_scanned_fraction"] <= 1.0
+    if cloud in ("clustered", "lowdim") and n >= 30000:
+        assert stats["leaves_scanned_fraction"] < 0.9, stats       # the bound does prune where directions cluster
+    if n <= 5000:
+        wv, wi = oracle.knn_bruteforce_angular(pts, qry, 16, 1000)
+        v, i = knn.unpack_signed_keys(got)
+        assert (i.cpu().numpy() == wi).all() and (v.cpu().numpy().view(np.uint32) == wv.view(np.uint32)).all()
+
+
+@pytest.mark.gpu
 def test_tree_argument_errors(ctx, torch_cuda):
     torch = torch_cuda
     from raytracer_amd import capi, knn_tree
