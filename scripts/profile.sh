@@ -32,6 +32,10 @@ for wl in box tri euclid angular; do
     run "valu_$wl" 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d "$OUT/pmc_valu_$wl" -- $BENCH --only $wl --steps 3 --warmup 1
     run "grbm_$wl" 120 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_grbm_$wl" -- $BENCH --only $wl --steps 3 --warmup 1
 done
+# short angular segments (the quarters of a mixed batch) run the chained kernel: a pass of its own, keyed by kernel name in traffic.json
+for c in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "valu:SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES" "grbm:GRBM_GUI_ACTIVE"; do
+    run "${c%%:*}_angular_short" 120 rocprofv3 --pmc ${c#*:} --output-format csv -d "$OUT/pmc_${c%%:*}_angular_short" -- $BENCH --only angular --log2-ops 22 --steps 3 --warmup 1
+done
 # the drivers above the op kernels: record stream (both modes), k-NN (exhaustive and tree), traversal (both walks)
 for spec in "stream1:--only stream --stream-mode 1" "stream2:--only stream --stream-mode 2" "knn_exhaustive:--only knn --knn-tree 0" \
             "knn_tree_walk:--only knn --knn-tree 1" "knn_tree_leafmajor:--only knn --knn-tree 2" "trace_dfs:--only trace" "trace_dfs_sorted:--only trace --trace-sorted 1" "trace_wavefront:--only trace --trace-wavefront 1" "trace_device_built:--only trace --trace-build device" \
