@@ -347,6 +347,19 @@ static void device_knn(rt_dp_ctx *ctx) {
         CHECK(rt_dp_knn_home_leaf(ctx, d_q.p, nq, nl, b_sd.p, b_sv.p, b_home.p, nullptr) == RT_DP_OK, "home leaf on the device: %s", rt_dp_last_error());
         CHECK(rt_dp_knn_angular16(ctx, d_pts.p, n, d_q.p, nq, 0, 1, d_neg.p, d_out2.p, nullptr) == RT_DP_OK, "knn angular: %s", rt_dp_last_error());
         CHECK(rt_dp_synchronize(ctx) == RT_DP_OK, "synchronize");
+        // the angular ranking through the tree: the exhaustive lists again
+        Dev<float> d_neg2((size_t)nq * 16);
+        Dev<uint32_t> d_bound2(nq), d_out4((size_t)nq * 16);
+        Dev<unsigned long long> d_scanned(1);
+        CHECK(hipMemset(d_scanned.p, 0, 8) == hipSuccess, "memset");
+        CHECK(rt_dp_knn_tree_angular16(ctx, &tree, d_q.p, d_home.p, nq, 1, d_bound2.p, d_neg2.p, d_out4.p, reinterpret_cast<uint64_t *>(d_scanned.p), nullptr) == RT_DP_OK,
+              "knn angular tree: %s", rt_dp_last_error());
+        CHECK(rt_dp_synchronize(ctx) == RT_DP_OK, "synchronize");
+        {
+            const auto e = d_neg.down(), t = d_neg2.down();
+            CHECK(same_bits(e.data(), t.data(), e.size()) && d_out2.down() == d_out4.down(), "angular tree != angular exhaustive at n=%u", n);
+            CHECK(d_scanned.down()[0] > 0, "no leaf scanned");
+        }
         CHECK(rt_dp_knn_euclid16(ctx, d_pts.p + 1, n, d_q.p, nq, 0, 1, d_dist.p, d_out.p, nullptr) == RT_DP_EALIGN, "misaligned points accepted");
         CHECK(rt_dp_knn_euclid16(ctx, nullptr, n, d_q.p, nq, 0, 1, d_dist.p, d_out.p, nullptr) == RT_DP_ENULL, "NULL points accepted");
     }
@@ -460,6 +473,70 @@ static void device_streams_and_compaction(rt_dp_ctx *ctx) {
     for (auto *d : ops) delete d;
 }
 
+// The shard planners, several contexts driven from the plan, the kernel names, and the repair of a forced give-up.
+static void sharding_and_giveups(rt_dp_ctx *ctx) {
+    const HostBatch h = make(20000, 15000, 9000, 7000, 77);
+    HostResults whole, parts;
+    rt_dp_op_batch in; rt_dp_result_batch out;
+    std::memset(&in, 0, sizeof in); std::memset(&out, 0, sizeof out);
+    in.struct_size = sizeof in; out.struct_size = sizeof out;
+    fill_plain(h, in);
+    fill_results(h, whole, out);
+    CHECK(rt_dp_reset(ctx) == RT_DP_OK && rt_dp_eval_ctx(ctx, &in, &out) == RT_DP_OK, "whole stream: %s", rt_dp_last_error());
+    char name[128];
+    for (int op = 0; op < 4; ++op) {
+        CHECK(rt_dp_kernel_name(ctx, &in, &out, op, name, sizeof name) == RT_DP_OK && std::strncmp(name, "rtdp::k_", 8) == 0, "kernel name of opcode %d: '%s'", op, name);
+    }
+    CHECK(rt_dp_kernel_name(ctx, &in, &out, 7, name, sizeof name) == RT_DP_EOPCODE, "opcode 7 named");
+    for (uint32_t world : {1u, 3u, 5u}) {
+        std::vector<rt_dp_shard_range> plan(world);
+        const uint64_t n[4] = {h.n_tri, h.n_box, h.n_euc, h.n_ang};
+        CHECK(rt_dp_shard_plan(n, h.ectl.data(), h.actl.data(), world, 0, plan.data()) == RT_DP_OK, "shard plan: %s", rt_dp_last_error());
+        rt_dp_result_batch pout;
+        std::memset(&pout, 0, sizeof pout); pout.struct_size = sizeof pout;
+        fill_results(h, parts, pout);
+        for (uint32_t r = 0; r < world; ++r) {
+            rt_dp_ctx *c = nullptr;
+            CHECK(rt_dp_create(nullptr, &c) == RT_DP_OK, "create: %s", rt_dp_last_error());
+            rt_dp_op_batch pin = in; rt_dp_result_batch po = pout;
+            const uint64_t t0 = plan[r].start[0], b0 = plan[r].start[1], e0 = plan[r].start[2], a0 = plan[r].start[3];
+            for (int op = 0; op < 4; ++op) pin.n[op] = plan[r].stop[op] - plan[r].start[op];
+            for (int a = 0; a < 3; ++a) { pin.box.org[a] += b0; pin.box.dir[a] += b0; pin.box.inv[a] += b0; pin.tri.org[a] += t0; pin.tri.shear[a] += t0; }
+            pin.box.extent += b0;
+            for (int b = 0; b < 4; ++b) for (int f = 0; f < 6; ++f) pin.box.aabb[b][f] += b0;
+            for (int v = 0; v < 3; ++v) for (int a = 0; a < 3; ++a) pin.tri.vtx[v][a] += t0;
+            pin.tri.k += t0;
+            pin.euc.a += e0 * 16; pin.euc.b += e0 * 16; pin.euc.ctl += e0; pin.ang.a += a0 * 8; pin.ang.b += a0 * 8; pin.ang.ctl += a0;
+            for (int k = 0; k < 4; ++k) po.box.tmin_out[k] += b0;
+            po.box.flags += b0; po.tri.t_num += t0; po.tri.t_denom += t0; po.tri.hit += t0;
+            po.euc.accumulator += e0; po.ang.dot_product += a0; po.ang.norm += a0;
+            CHECK(rt_dp_eval_ctx(c, &pin, &po) == RT_DP_OK, "part %u of %u: %s", r, world, rt_dp_last_error());
+            rt_dp_destroy(c);
+        }
+        CHECK(same_bits(out.euc.accumulator, pout.euc.accumulator, h.n_euc) && same_bits(out.ang.dot_product, pout.ang.dot_product, h.n_ang) &&
+              same_bits(out.ang.norm, pout.ang.norm, h.n_ang) && same_bits(out.box.tmin_out[2], pout.box.tmin_out[2], h.n_box) &&
+              same_bits(out.tri.t_num, pout.tri.t_num, h.n_tri), "parts != whole stream at world %u", world);
+    }
+    CHECK(rt_dp_shard_plan(nullptr, nullptr, nullptr, 2, 0, nullptr) == RT_DP_ENULL, "NULL plan accepted");
+    {
+        const auto rec = records(5000, 91);
+        std::vector<uint64_t> cuts(5);
+        CHECK(rt_dp_shard_plan_records(rec.data(), rec.size(), 4, cuts.data()) == RT_DP_OK && cuts[0] == 0 && cuts[4] == rec.size(), "record plan: %s", rt_dp_last_error());
+        CHECK(rt_dp_shard_plan_records(rec.data(), rec.size(), 0, cuts.data()) == RT_DP_EINVAL, "world 0 accepted");
+    }
+    // a forced give-up of the hand-over between workgroups: repaired by the synchronous entry point, same bits
+    HostResults again;
+    rt_dp_result_batch aout;
+    std::memset(&aout, 0, sizeof aout); aout.struct_size = sizeof aout;
+    fill_results(h, again, aout);
+    CHECK(rt_dp_set_option(ctx, "debug_chain_skip", 1) == RT_DP_OK, "hook");
+    CHECK(rt_dp_reset(ctx) == RT_DP_OK && rt_dp_eval_ctx(ctx, &in, &aout) == RT_DP_OK, "batch behind a give-up: %s", rt_dp_last_error());
+    int fallbacks = 0;
+    CHECK(rt_dp_get_option(ctx, "chain_fallbacks", &fallbacks) == RT_DP_OK && fallbacks >= 1, "no fallback counted (%d)", fallbacks);
+    CHECK(same_bits(out.euc.accumulator, aout.euc.accumulator, h.n_euc) && same_bits(out.ang.dot_product, aout.ang.dot_product, h.n_ang), "repair changed bits");
+    CHECK(rt_dp_set_option(ctx, "debug_chain_skip", -1) == RT_DP_OK, "hook off");
+}
+
 static void default_context_thread(int id) {
     const HostBatch h = make(1000 + id, 10, 100, 100, 40u + id);
     rt_dp_op_batch in;
@@ -491,6 +568,8 @@ int main() {
     std::printf("traversal entry points done\n");
     device_streams_and_compaction(ctx);
     std::printf("device streams and compaction done\n");
+    sharding_and_giveups(ctx);
+    std::printf("shard plans, several contexts and give-up repair done\n");
     for (int k = 0; k < 20; ++k) {
         rt_dp_ctx *c = nullptr;
         CHECK(rt_dp_create(nullptr, &c) == RT_DP_OK, "create %d: %s", k, rt_dp_last_error());

@@ -13,7 +13,7 @@ case "$1" in
 build)
     mkdir -p "$SAN"
     srcs=""
-    for s in kernels.hip knn.hip stream.hip stream_fused.hip trace.hip compact.hip pairs.hip build_device.hip build_kd.hip api.cpp build_index.cpp; do srcs="$srcs $CSRC/$s"; done
+    for s in kernels.hip knn.hip stream.hip stream_fused.hip trace.hip compact.hip pairs.hip build_device.hip build_kd.hip api.cpp build_index.cpp shard.cpp; do srcs="$srcs $CSRC/$s"; done
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -x hip -O1 -g -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-gpu-flush-denormals-to-zero \
         -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host -fno-omit-frame-pointer \
         -I "$ROOT/include" -I "$CSRC" -shared -o "$SAN/librt_dp.so" $srcs || exit 1
