@@ -40,6 +40,7 @@ struct StreamSide {
     float *sum0, *sum1;   // [n]   tree sums of a distance beat (Euclidean: sum0; angular: dot, norm)
     uint32_t *rbits[2];   // [ceil(n / 2048)] bit b of word w: records [(32 w + b) * 64, +64) hold a reset of opcode 2 / 3
     uint32_t *flags;      // [1] opcode 2 present, [2] opcode 3 present (per launch); [8] an opcode > 3 was seen (sticky)
+    uint8_t *wavebits;    // [ceil(n / 64)] per wave of k_stream_eval: 1 / 2 = a beat of opcode 2 / 3 occurs, 4 / 8 = one with its reset bit
 };
 
 __device__ __forceinline__ float tree16(const float (&s)[16]) {  // (i, i+8), (i, i+4), (i, i+2), (0, 1)
@@ -173,16 +174,130 @@ __device__ __forceinline__ void stream_wave_walk(unsigned long long todo, unsign
     }
 }
 
+// ---- compact staging ---------------------------------------------------------------------------------------------
+// A record is 21 chunks of 16 bytes, but an opcode reads at most 11 of them (Quadbox: ray origin / dir / inv / extent, the four
+// boxes and the reset word; triangle 8; Euclidean beat 9; angular beat 7).  The evaluation kernel is bound by how many waves'
+// record buffers fit a CU's LDS, so the wave keeps only the live chunks: the coalesced loads fetch whole records as before
+// (the lines come in full anyway), the lane that holds a record's chunk 0 posts its opcode, and then every lane files each
+// chunk it holds under slot = number of live chunks of that record's opcode below it -- or drops it.  Records are 11 slots
+// apart (odd: the lanes' 16-byte reads of their own record spread over all banks): 11 KiB per wave instead of 21, twice the
+// resident waves.
+constexpr int kLiveStride = 11;  // slots per record
+constexpr uint32_t kLiveBox = 0x1007F7u;   // chunks 0 1 2, 4..10, 20
+constexpr uint32_t kLiveTri = 0x101C1Du;   // chunks 0, 2 3 4, 10 11 12, 20
+constexpr uint32_t kLiveEuc = 0x1FF000u;   // chunks 12..20
+constexpr uint32_t kLiveAng = 0x177000u;   // chunks 12 13 14, 16 17 18, 20
+
+__device__ __forceinline__ uint32_t live_chunks(uint32_t op) {
+    return op == 1u ? kLiveBox : op == 0u ? kLiveTri : op == 2u ? kLiveEuc : op == 3u ? kLiveAng : 0u;
+}
+
+// stream_eval_record over the compact slots of the lane's record (rc = 11 slots).  Same arithmetic, same outputs.
+__device__ __forceinline__ bool stream_eval_compact(const u4v *rc, uint32_t op_in, bool have, int extended, uint32_t (&w)[kRecOut], uint32_t &op,
+                                                    uint32_t &reset, float &sum0, float &sum1) {
+    bool known = true;
+    op = have ? op_in : 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < kRecOut; ++k) w[k] = 0u;
+    sum0 = 0.0f;
+    sum1 = 0.0f;
+    reset = 0u;
+    if (op == 1u) {  // slots: chunks 0 1 2 | 4..10 | 20
+        uint32_t W[44];
+        const u4v c0 = rc[0], c1 = rc[1], c2 = rc[2];
+        W[1] = c0.y; W[2] = c0.z; W[3] = c0.w;
+        W[4] = c1.x; W[5] = c1.y; W[6] = c1.z; W[7] = c1.w;
+        W[8] = c2.x; W[9] = c2.y; W[10] = c2.z; W[11] = c2.w;
+#pragma unroll
+        for (int c = 4; c <= 10; ++c) {
+            const u4v v = rc[c - 1];
+            W[4 * c] = v.x; W[4 * c + 1] = v.y; W[4 * c + 2] = v.z; W[4 * c + 3] = v.w;
+        }
+        reset = rc[10].w & 1u;
+        float r[kBoxFields], t[4];
+#pragma unroll
+        for (int f = 0; f < 10; ++f) r[f] = __uint_as_float(W[1 + f]);
+#pragma unroll
+        for (int f = 0; f < 24; ++f) r[10 + f] = __uint_as_float(W[17 + f]);
+        uint32_t fl;
+        box_one(r, t, fl);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            w[1 + k] = __float_as_uint(t[k]);
+            w[5 + k] = (fl >> k) & 1u;
+            w[9 + k] = (fl >> (4 + 2 * k)) & 3u;
+        }
+    } else if (op == 0u) {  // slots: chunks 0 | 2 3 4 | 10 11 12 | 20
+        const u4v c0 = rc[0], c2 = rc[1], c3 = rc[2], c4 = rc[3], c10 = rc[4], c11 = rc[5], c12 = rc[6];
+        reset = rc[7].w & 1u;
+        float r[kTriFields];
+        r[0] = __uint_as_float(c0.y); r[1] = __uint_as_float(c0.z); r[2] = __uint_as_float(c0.w);
+        r[3] = __uint_as_float(c3.z); r[4] = __uint_as_float(c3.w); r[5] = __uint_as_float(c4.x);
+        r[6] = __uint_as_float(c10.y); r[7] = __uint_as_float(c10.z); r[8] = __uint_as_float(c10.w);
+        r[9] = __uint_as_float(c11.x); r[10] = __uint_as_float(c11.y); r[11] = __uint_as_float(c11.z); r[12] = __uint_as_float(c11.w);
+        r[13] = __uint_as_float(c12.x); r[14] = __uint_as_float(c12.y);
+        const uint32_t kw = (c2.w & 3u) | ((c3.x & 3u) << 2) | ((c3.y & 3u) << 4);
+        float num, den;
+        uint32_t hit;
+        tri_one(r, kw, num, den, hit);
+        w[13] = __float_as_uint(num);
+        w[14] = __float_as_uint(den);
+        w[15] = hit;
+    } else if (op == 2u) {  // slots: chunks 12..20 = words 48..83
+        uint32_t W[36];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const u4v v = rc[c];
+            W[4 * c] = v.x; W[4 * c + 1] = v.y; W[4 * c + 2] = v.z; W[4 * c + 3] = v.w;
+        }
+        reset = W[35] & 1u;
+        const uint32_t mask = W[34];
+        float s[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool on = (mask >> i) & 1u;
+            const float d = on ? (__uint_as_float(W[2 + i]) - __uint_as_float(W[18 + i])) : 0.0f;  // :221-245
+            s[i] = d * d;                                                                            // :399-419
+        }
+        sum0 = tree16(s);
+    } else if (op == 3u) {  // slots: chunks 12 13 14 | 16 17 18 | 20
+        const u4v c12 = rc[0], c13 = rc[1], c14 = rc[2], c16 = rc[3], c17 = rc[4], c18 = rc[5], c20 = rc[6];
+        reset = c20.w & 1u;
+        const uint32_t A[8] = {c12.z, c12.w, c13.x, c13.y, c13.z, c13.w, c14.x, c14.y};
+        const uint32_t B[8] = {c16.z, c16.w, c17.x, c17.y, c17.z, c17.w, c18.x, c18.y};
+        const uint32_t mask = c20.z;
+        float s[8], m[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool on = (mask >> i) & 1u;
+            const float q = on ? __uint_as_float(A[i]) : 0.0f;  // :246-268
+            const float c = on ? __uint_as_float(B[i]) : 0.0f;
+            s[i] = q * c;                                        // :420-453
+            m[i] = c * c;
+        }
+        sum0 = tree8(s);
+        sum1 = tree8(m);
+    } else if (have) {
+        known = false;  // cannot occur in the RTL's 2-bit field
+    }
+    if (have) {
+        w[0] = op;
+        if (extended) { w[17] = reset; w[20] = reset; }
+    }
+    return known;
+}
+
 __global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__ in, uint64_t n, int extended, uint32_t *__restrict__ out,
                                                     StreamSide side) {
-    __shared__ __align__(16) uint32_t s_rec[kWaveRecs * kRecIn];  // 21 KiB; re-used for the output records
+    __shared__ __align__(16) uint32_t s_rec[kWaveRecs * kLiveStride * 4];  // 11 KiB of live chunks; re-used for the output records (5.25 KiB)
+    __shared__ uint32_t s_op[kWaveRecs];
     const int lane = threadIdx.x;
     const uint64_t r0 = (uint64_t)blockIdx.x * kWaveRecs;
     const uint32_t live = (n - r0 < (uint64_t)kWaveRecs) ? (uint32_t)(n - r0) : (uint32_t)kWaveRecs;
 
-    // coalesced copy of the wave's records into LDS (record r, word w -> s_rec[84 r + w]).  Whole records: fetching only the
-    // 16-byte chunks a record's opcode reads (44 % of them on a uniform mix; opcodes first, then predicated loads, with or
-    // without the opcodes of the next tile fetched ahead) measured 9-11 % slower on MI355X -- the lines come in full anyway
+    // Coalesced loads of the wave's whole records (chunk g = j * 64 + lane of its 21 KiB); fetching only the chunks a record's
+    // opcode reads measured 9-11 % slower on MI355X -- the lines come in full anyway.  Chunk g belongs to record g / 21; 64 = 3 * 21 + 1,
+    // so from one load to the next a lane moves three records on and one chunk up (four records on where the chunk wraps).
     {
         const u4v *src = reinterpret_cast<const u4v *>(in + r0 * kRecIn);
         const uint32_t chunks = live * (kRecIn / 4);
@@ -192,15 +307,33 @@ __global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__
             const uint32_t g = (uint32_t)j * 64u + lane;
             v[j] = (g < chunks) ? __builtin_nontemporal_load(src + g) : u4v{0u, 0u, 0u, 0u};
         }
+        const uint32_t rec0 = (uint32_t)lane / 21u, chunk0 = (uint32_t)lane % 21u;
+        // the lane that holds a record's first chunk posts its opcode
 #pragma unroll
-        for (int j = 0; j < kRecIn / 4; ++j) reinterpret_cast<u4v *>(s_rec)[j * 64 + lane] = v[j];
+        for (int j = 0; j < kRecIn / 4; ++j) {
+            const uint32_t wrap = (chunk0 + (uint32_t)j >= 21u) ? 1u : 0u;
+            const uint32_t c = chunk0 + (uint32_t)j - 21u * wrap, r = rec0 + 3u * (uint32_t)j + wrap;
+            if (c == 0u && r < (uint32_t)kWaveRecs) s_op[r] = v[j].x;
+        }
+        __syncthreads();
+        // every chunk goes to its slot in its record's compact row, or nowhere
+#pragma unroll
+        for (int j = 0; j < kRecIn / 4; ++j) {
+            const uint32_t wrap = (chunk0 + (uint32_t)j >= 21u) ? 1u : 0u;
+            const uint32_t c = chunk0 + (uint32_t)j - 21u * wrap, r = rec0 + 3u * (uint32_t)j + wrap;
+            if (r < live) {
+                const uint32_t m = live_chunks(s_op[r]);
+                if ((m >> c) & 1u) reinterpret_cast<u4v *>(s_rec)[r * kLiveStride + __popc(m & ((1u << c) - 1u))] = v[j];
+            }
+        }
     }
     __syncthreads();
 
     const bool have = (uint32_t)lane < live;
     uint32_t w[kRecOut], op, reset;
     float sum0, sum1;
-    if (!stream_eval_record(s_rec, lane, have, extended, w, op, reset, sum0, sum1)) atomicOr(&side.flags[8], 1u);
+    if (!stream_eval_compact(reinterpret_cast<const u4v *>(s_rec) + lane * kLiveStride, s_op[lane], have, extended, w, op, reset, sum0, sum1))
+        atomicOr(&side.flags[8], 1u);
 
     // Beats behind the first reset of their opcode in this wave start from +0 whatever came before: their accumulator
     // outputs are final here and travel with the record's coalesced store.  Only the beats in front of the first reset
@@ -234,14 +367,10 @@ __global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__
     {
         const unsigned long long e = __ballot(op == 2u), a = __ballot(op == 3u);
         const unsigned long long er = __ballot(op == 2u && reset), ar = __ballot(op == 3u && reset);
-        if (lane == 0) {
-            const uint32_t word = blockIdx.x >> 5, bit = 1u << (blockIdx.x & 31u);
-            if (er) atomicOr(&side.rbits[0][word], bit);
-            if (ar) atomicOr(&side.rbits[1][word], bit);
-            // thousands of waves would queue up on these two words: raise a flag only while it still reads 0
-            if (e && !__hip_atomic_load(&side.flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&side.flags[1], 1u);
-            if (a && !__hip_atomic_load(&side.flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&side.flags[2], 1u);
-        }
+        // What the fold needs to know about this wave, as one plain byte: no atomic and no device-scope read in the life of a
+        // wave (an earlier form set summary bits and launch flags with atomics guarded by a device-scope load of the flag: one
+        // more memory round trip per wave).  k_stream_bits turns the bytes into the summary words and the launch flags.
+        if (lane == 0) side.wavebits[blockIdx.x] = (uint8_t)((e ? 1u : 0u) | (a ? 2u : 0u) | (er ? 4u : 0u) | (ar ? 8u : 0u));
     }
 
     __syncthreads();  // every lane has read its record: the buffer now takes the output records
@@ -257,6 +386,30 @@ __global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__
         }
     } else {
         for (uint32_t g = lane; g < live * kRecOut; g += 64) dst[g] = s_rec[g];
+    }
+}
+
+// The per-wave bytes of k_stream_eval become the reset summaries (one bit per 64 records) and the "opcode occurs" flags.
+__global__ __launch_bounds__(256) void k_stream_bits(StreamSide side, uint64_t nblk) {
+    const uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x, nwords = (nblk + 31) >> 5;
+    uint32_t r0 = 0u, r1 = 0u, any = 0u;
+    if (w < nwords) {
+        const u4v lo = reinterpret_cast<const u4v *>(side.wavebits)[2 * w], hi = reinterpret_cast<const u4v *>(side.wavebits)[2 * w + 1];
+        const uint32_t words[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int b = 0; b < 32; ++b) {
+            const uint32_t byte = (w * 32 + b < nblk) ? ((words[b >> 2] >> (8 * (b & 3))) & 0xFFu) : 0u;  // bytes behind the last wave are stale
+            any |= byte;
+            r0 |= ((byte >> 2) & 1u) << b;
+            r1 |= ((byte >> 3) & 1u) << b;
+        }
+        side.rbits[0][w] = r0;
+        side.rbits[1][w] = r1;
+    }
+    const int any2 = __syncthreads_or((int)(any & 1u)), any3 = __syncthreads_or((int)(any & 2u));
+    if (threadIdx.x == 0) {
+        if (any2) atomicOr(&side.flags[1], 1u);
+        if (any3) atomicOr(&side.flags[2], 1u);
     }
 }
 
@@ -645,6 +798,7 @@ static StreamSide stream_fused_layout(char *workspace, uint64_t capacity, size_t
     side.sum1 = ws_at<float>(workspace, o); o += up(capacity * 4);
     side.rbits[0] = ws_at<uint32_t>(workspace, o); o += up(nwords * 4);
     side.rbits[1] = ws_at<uint32_t>(workspace, o); o += up(nwords * 4);
+    side.wavebits = ws_at<uint8_t>(workspace, o); o += up(nwords * 32);  // whole 32-byte groups: k_stream_bits reads them with 16-byte loads
     side.flags = ws_at<uint32_t>(workspace, o);
     if (bits_bytes) *bits_bytes = 2 * up(nwords * 4);
     return side;
@@ -663,9 +817,10 @@ hipError_t stream_fused_eval(const uint32_t *in, uint64_t n, uint64_t capacity, 
     const StreamSide side = stream_fused_layout(workspace, capacity, &bits);
     const uint64_t nblk = (n + 63) / 64;
     if (n > capacity || nblk > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(side.rbits[0], 0, bits + (first_piece ? 256 : 32), s);  // both bit arrays and the per-piece flags (all flags on the first piece)
+    hipError_t e = hipMemsetAsync(side.flags, 0, first_piece ? 256 : 32, s);  // the per-piece flags (all flags on the first piece)
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_stream_eval, dim3((unsigned)nblk), dim3(64), 0, s, in, n, extended, out, side);
+    hipLaunchKernelGGL(k_stream_bits, dim3((unsigned)(((nblk + 31) / 32 + 255) / 256)), dim3(256), 0, s, side, nblk);
     view->tag = side.tag; view->sum0 = side.sum0; view->sum1 = side.sum1;
     view->rbits[0] = side.rbits[0]; view->rbits[1] = side.rbits[1]; view->flags = side.flags;
     return hipGetLastError();
