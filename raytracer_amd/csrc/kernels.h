@@ -101,9 +101,9 @@ hipError_t launch_knn_euclid16(const float *pts, uint32_t n_pts, const float *qr
                                uint32_t splits, bool angular, float *out_d, uint32_t *out_i, hipStream_t stream);
 // fused record-stream path (stream_fused.hip)
 struct StreamSideView {
-    const uint32_t *tag;
     const float *sum0, *sum1;
-    const uint32_t *rbits[2];
+    const void *heads, *tails;              // 16 bytes per evaluation wave each
+    const unsigned long long *occ[2], *rst[2];
     const uint32_t *flags;  // [1] opcode 2 present, [2] opcode 3 present (per launch); [8] opcode > 3 seen (sticky, cleared by the caller)
 };
 size_t stream_fused_workspace(uint64_t capacity);

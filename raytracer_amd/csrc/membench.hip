@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <cstring>
 #include <algorithm>
 
 typedef float f2v __attribute__((ext_vector_type(2)));
@@ -140,6 +141,64 @@ template <typename T, int RS, int WS, bool WIDE> static void run_mix(const char 
     printf("%-28s %8.1f GB/s  (%.3f ms, %d read + %d write streams)\n", name, b / ms / 1e6, ms, RS, WS);
 }
 
+
+// The record-stream pattern: a wave reads RECS consecutive 336-byte records (coalesced 16-byte loads, chunk g = j * 64 + lane)
+// and writes RECS 84-byte records; THREADS per workgroup, every wave with a span of its own.  No arithmetic beyond what keeps
+// the loads alive.
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+template <int THREADS, int RECS, bool NT_LD, bool NT_ST>
+__global__ __launch_bounds__(THREADS) void k_rec(const u4v *in, u4v *out, size_t n_rec) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
+    const size_t r0 = wave * RECS;
+    if (r0 >= n_rec) return;
+    constexpr int kIn = RECS * 21, kOut = (RECS * 21) / 4;  // chunks of 16 bytes
+    const u4v *src = in + r0 * 21;
+    u4v acc = u4v{0u, 0u, 0u, 0u};
+    u4v v[(kIn + 63) / 64];
+#pragma unroll
+    for (int j = 0; j < (kIn + 63) / 64; ++j) {
+        const int g = j * 64 + lane;
+        v[j] = u4v{0u, 0u, 0u, 0u};
+        if (g < kIn) v[j] = NT_LD ? __builtin_nontemporal_load(src + g) : src[g];
+    }
+#pragma unroll
+    for (int j = 0; j < (kIn + 63) / 64; ++j) acc ^= v[j];
+    u4v *dst = out + (r0 * 21) / 4;
+#pragma unroll
+    for (int j = 0; j < (kOut + 63) / 64; ++j) {
+        const int g = j * 64 + lane;
+        if (g < kOut) {
+            if (NT_ST) __builtin_nontemporal_store(acc, dst + g);
+            else dst[g] = acc;
+        }
+    }
+}
+
+template <int THREADS, int RECS, bool NT_LD, bool NT_ST> static void run_rec(const char *name, const void *in, void *out, size_t n_rec, unsigned lds) {
+    const size_t waves = (n_rec + RECS - 1) / RECS;
+    const unsigned blocks = (unsigned)((waves + THREADS / 64 - 1) / (THREADS / 64));
+    double ms = time_ms([&] { hipLaunchKernelGGL((k_rec<THREADS, RECS, NT_LD, NT_ST>), dim3(blocks), dim3(THREADS), lds, 0, (const u4v *)in, (u4v *)out, n_rec); });
+    printf("%-44s lds %6u  %8.1f GB/s  (%.3f ms, 420 B per record)\n", name, lds, n_rec * 420.0 / ms / 1e6, ms);
+}
+
+static void rec_probes(void *a, void *b, size_t bytes) {
+    size_t n_rec = bytes / 336;
+    if (n_rec > ((size_t)1 << 24)) n_rec = (size_t)1 << 24;
+    const unsigned caps[] = {0u, 11520u, 21504u, 32768u, 65536u};
+    for (unsigned lds : caps) {
+        run_rec<64, 64, true, true>("rec 64 thr, 64 rec/wave, nt ld, nt st", a, b, n_rec, lds);
+        run_rec<64, 64, false, true>("rec 64 thr, 64 rec/wave, ld, nt st", a, b, n_rec, lds);
+        run_rec<64, 64, true, false>("rec 64 thr, 64 rec/wave, nt ld, st", a, b, n_rec, lds);
+        run_rec<64, 64, false, false>("rec 64 thr, 64 rec/wave, ld, st", a, b, n_rec, lds);
+        run_rec<256, 64, true, true>("rec 256 thr, 64 rec/wave, nt ld, nt st", a, b, n_rec, lds);
+        run_rec<64, 32, true, true>("rec 64 thr, 32 rec/wave, nt ld, nt st", a, b, n_rec, lds);
+        run_rec<256, 32, true, true>("rec 256 thr, 32 rec/wave, nt ld, nt st", a, b, n_rec, lds);
+        run_rec<64, 16, true, true>("rec 64 thr, 16 rec/wave, nt ld, nt st", a, b, n_rec, lds);
+        run_rec<256, 16, true, true>("rec 256 thr, 16 rec/wave, nt ld, nt st", a, b, n_rec, lds);
+    }
+}
+
 int main(int argc, char **argv) {
     // second argument: resident 256-thread workgroups per CU (LDS granules of 1280 B, 128 per CU); 0 = whatever fits
     if (argc > 2 && atoi(argv[2]) >= 3) g_lds = (128u / (unsigned)atoi(argv[2])) * 1280u;
@@ -150,6 +209,12 @@ int main(int argc, char **argv) {
     CK(hipMemset(a, 0x11, bytes));
     CK(hipMemset(b, 0x22, bytes));
     CK(hipDeviceSynchronize());
+    if (argc > 3 && !strcmp(argv[3], "rec")) {  // only the record-stream pattern
+        rec_probes(a, b, bytes);
+        CK(hipFree(a));
+        CK(hipFree(b));
+        return 0;
+    }
     run_read<float, false, 1>("read dword 1 stream", a, b, bytes);
     run_read<float, true, 1>("read dword nt 1 stream", a, b, bytes);
     run_read<f2v, false, 1>("read dwordx2 1 stream", a, b, bytes);

@@ -4,25 +4,34 @@
 // way to the same bits).
 //
 //   k_stream_eval   one wave per 64 consecutive records.  The wave copies its 21 KiB of
-//                   records into LDS with coalesced 16-byte loads (a lane-per-record read
-//                   would touch 64 cache lines per instruction), then each lane evaluates
-//                   its own record: Quadbox and triangle ops completely; for a distance beat
-//                   the tree sum(s) of the beat, which do not depend on the accumulator.
-//                   The 21-word output records go back through LDS to coalesced stores.
-//                   Side arrays receive, per record, tag = opcode | reset << 2 and the
-//                   beat's tree sums, plus one bit per 64 records and distance opcode
-//                   saying "a reset of this opcode occurs here".
-//   k_stream_fold   per distance opcode: the accumulator is a strictly sequential float sum
-//                   over the beats of one vector pair IN STREAM ORDER (reference
+//                   records through registers into LDS with coalesced 16-byte loads (a
+//                   lane-per-record read would touch 64 cache lines per instruction), keeping
+//                   only the chunks the record's opcode reads; then each lane evaluates its own
+//                   record: Quadbox and triangle ops completely; for a distance beat the tree
+//                   sum(s) of the beat, which do not depend on the accumulator.  The accumulator
+//                   is a strictly sequential float sum over the beats of one vector pair IN
+//                   STREAM ORDER (reference
 //                   src/main/scala/raytracer_datapath/UnifiedDatapath.scala:1133-1154,
-//                   :1028-1064), so a workgroup owns whole pairs: its range of records runs
-//                   from the first pair boundary at or after blockIdx * tile to the first one
-//                   at or after (blockIdx + 1) * tile (a boundary follows a record of this
-//                   opcode that carries the reset bit; found through the bit summaries, so
-//                   long stretches without one cost 128 Ki records per step).  Inside a
-//                   sub-tile the opcode's beats are compacted into LDS in stream order, one
-//                   lane per pair adds them up, and the results are patched into the output
-//                   records.
+//                   :1028-1064): beats behind the first reset of their opcode inside the wave
+//                   start from +0 whatever came before, so the wave finishes them itself.  Left
+//                   over are the HEAD beats of the wave (those up to and including its first
+//                   reset; all of them when it holds no reset): they continue a pair from an
+//                   earlier wave.  The 21-word output records go back through LDS to coalesced
+//                   stores.  Per wave and distance opcode the side arrays receive the head
+//                   lanes as a 64-bit mask, the TAIL sum (the running sum behind the wave's last
+//                   record, counted from its last reset), the beats' tree sums as rows of 64,
+//                   and one byte saying which distance opcodes occur with / without a reset.
+//   k_stream_bits   turns the bytes into one bit per wave (64 waves per word) and the
+//                   "opcode occurs" flags.
+//   k_stream_fold   per distance opcode: a workgroup of one wave is in charge of the pairs that
+//                   run out of the 64 evaluation waves of its range, i.e. of every head beat
+//                   behind the first reset-holding wave of the range up to and including the
+//                   heads of the first reset-holding wave behind the range.  It walks those
+//                   waves in order (rows are fetched eight waves at a time, the walk itself
+//                   runs in registers), re-seeds the running sum with the tail of every
+//                   reset-holding wave it passes, and patches the results into the output
+//                   records.  Waves without a beat of the opcode are skipped through the bit
+//                   words, 256 Ki records per step where there are none for long.
 // Output fields of foreign opcodes are zero and the two *_reset_accum fields echo the input
 // bit for every opcode (:1205, :1254, :1267-1268).
 #include "ops.hpp"
@@ -36,11 +45,14 @@ constexpr int kRecOut = 21;   // words per rt_dp_output_bundle
 constexpr int kWaveRecs = 64;
 
 struct StreamSide {
-    uint32_t *tag;        // [n]   opcode | reset << 2 | outputs final << 3
-    float *sum0, *sum1;   // [n]   tree sums of a distance beat (Euclidean: sum0; angular: dot, norm)
-    uint32_t *rbits[2];   // [ceil(n / 2048)] bit b of word w: records [(32 w + b) * 64, +64) hold a reset of opcode 2 / 3
-    uint32_t *flags;      // [1] opcode 2 present, [2] opcode 3 present (per launch); [8] an opcode > 3 was seen (sticky)
-    uint8_t *wavebits;    // [ceil(n / 64)] per wave of k_stream_eval: 1 / 2 = a beat of opcode 2 / 3 occurs, 4 / 8 = one with its reset bit
+    float *sum0, *sum1;            // [n]   tree sums of a distance beat (Euclidean: sum0; angular: dot, norm); a wave's row of sum0 is written
+                                   //       when it holds head beats, its row of sum1 when it holds angular head beats
+    u4v *heads;                    // [ceil(n / 64)] per wave: head lanes of opcode 2 (x, y = low, high half), of opcode 3 (z, w)
+    u4v *tails;                    // [ceil(n / 64)] per wave: tail sums {Euclidean, angular dot, angular norm, unused}; valid where the wave holds a reset
+    uint8_t *wavebits;             // [ceil(n / 64)] per wave: 1 / 2 = a beat of opcode 2 / 3 occurs, 4 / 8 = one with its reset bit
+    unsigned long long *occ[2];    // [ceil(n / 4096)] bit b of word w: wave 64 w + b holds a beat of opcode 2 / 3
+    unsigned long long *rst[2];    // likewise: ... holds one with its reset bit
+    uint32_t *flags;               // [1] opcode 2 present, [2] opcode 3 present (per launch); [8] an opcode > 3 was seen (sticky)
 };
 
 __device__ __forceinline__ float tree16(const float (&s)[16]) {  // (i, i+8), (i, i+4), (i, i+2), (0, 1)
@@ -336,41 +348,39 @@ __global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__
         atomicOr(&side.flags[8], 1u);
 
     // Beats behind the first reset of their opcode in this wave start from +0 whatever came before: their accumulator
-    // outputs are final here and travel with the record's coalesced store.  Only the beats in front of the first reset
-    // (they continue a pair from an earlier wave) are left to k_stream_fold, which then has that many fewer 4-byte
-    // patches to write into finished records.
-    uint32_t fin = 0u;
+    // outputs are final here and travel with the record's coalesced store.  Only the head beats (up to and including the
+    // first reset; they continue a pair from an earlier wave) are left to k_stream_fold.
     if (extended) {
         const unsigned long long e2 = __ballot(op == 2u), r2 = __ballot(op == 2u && reset != 0u);
         const unsigned long long e3 = __ballot(op == 3u), r3 = __ballot(op == 3u && reset != 0u);
+        unsigned long long h2 = e2, h3 = e3;
+        float tail_e = 0.0f, tail_d = 0.0f, tail_n = 0.0f;
         if (r2) {
             const int lo = __ffsll((long long)r2) - 1;
-            const unsigned long long rest = e2 & ~((lo == 63) ? ~0ull : ((2ull << lo) - 1ull));
-            float a0 = 0.0f, a1 = 0.0f, res = 0.0f, none = 0.0f;
-            stream_wave_walk<false>(rest, r2, sum0, 0.0f, lane, a0, a1, res, none);
-            if ((rest >> lane) & 1ull) { w[16] = __float_as_uint(canon_nan(res)); fin = 1u; }
+            h2 = e2 & ((lo == 63) ? ~0ull : ((2ull << lo) - 1ull));
+            const unsigned long long rest = e2 & ~h2;
+            float none0 = 0.0f, res = 0.0f, none1 = 0.0f;
+            stream_wave_walk<false>(rest, r2, sum0, 0.0f, lane, tail_e, none0, res, none1);
+            if ((rest >> lane) & 1ull) w[16] = __float_as_uint(canon_nan(res));
         }
         if (r3) {
             const int lo = __ffsll((long long)r3) - 1;
-            const unsigned long long rest = e3 & ~((lo == 63) ? ~0ull : ((2ull << lo) - 1ull));
-            float a0 = 0.0f, a1 = 0.0f, res0 = 0.0f, res1 = 0.0f;
-            stream_wave_walk<true>(rest, r3, sum0, sum1, lane, a0, a1, res0, res1);
-            if ((rest >> lane) & 1ull) { w[18] = __float_as_uint(canon_nan(res0)); w[19] = __float_as_uint(canon_nan(res1)); fin = 1u; }
+            h3 = e3 & ((lo == 63) ? ~0ull : ((2ull << lo) - 1ull));
+            const unsigned long long rest = e3 & ~h3;
+            float res0 = 0.0f, res1 = 0.0f;
+            stream_wave_walk<true>(rest, r3, sum0, sum1, lane, tail_d, tail_n, res0, res1);
+            if ((rest >> lane) & 1ull) { w[18] = __float_as_uint(canon_nan(res0)); w[19] = __float_as_uint(canon_nan(res1)); }
         }
-    }
-
-    if (have) {
-        side.tag[r0 + lane] = (op & 3u) | (reset << 2) | (fin << 3);
-        side.sum0[r0 + lane] = sum0;
-        side.sum1[r0 + lane] = sum1;
-    }
-    {
-        const unsigned long long e = __ballot(op == 2u), a = __ballot(op == 3u);
-        const unsigned long long er = __ballot(op == 2u && reset), ar = __ballot(op == 3u && reset);
-        // What the fold needs to know about this wave, as one plain byte: no atomic and no device-scope read in the life of a
-        // wave (an earlier form set summary bits and launch flags with atomics guarded by a device-scope load of the flag: one
-        // more memory round trip per wave).  k_stream_bits turns the bytes into the summary words and the launch flags.
-        if (lane == 0) side.wavebits[blockIdx.x] = (uint8_t)((e ? 1u : 0u) | (a ? 2u : 0u) | (er ? 4u : 0u) | (ar ? 8u : 0u));
+        if (have && (h2 | h3)) side.sum0[r0 + lane] = sum0;
+        if (have && h3) side.sum1[r0 + lane] = sum1;
+        // What the fold needs to know about this wave: plain stores, no atomic and no device-scope read in the life of a
+        // wave (an earlier form set summary bits and launch flags with atomics guarded by a device-scope load of the flag:
+        // one more memory round trip per wave).
+        if (lane == 0) {
+            side.heads[blockIdx.x] = u4v{(uint32_t)h2, (uint32_t)(h2 >> 32), (uint32_t)h3, (uint32_t)(h3 >> 32)};
+            side.tails[blockIdx.x] = u4v{__float_as_uint(tail_e), __float_as_uint(tail_d), __float_as_uint(tail_n), 0u};
+            side.wavebits[blockIdx.x] = (uint8_t)((e2 ? 1u : 0u) | (e3 ? 2u : 0u) | (r2 ? 4u : 0u) | (r3 ? 8u : 0u));
+        }
     }
 
     __syncthreads();  // every lane has read its record: the buffer now takes the output records
@@ -389,175 +399,145 @@ __global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__
     }
 }
 
-// The per-wave bytes of k_stream_eval become the reset summaries (one bit per 64 records) and the "opcode occurs" flags.
+// The per-wave bytes of k_stream_eval become one bit per wave (64 waves per word) and the "opcode occurs" flags.
 __global__ __launch_bounds__(256) void k_stream_bits(StreamSide side, uint64_t nblk) {
-    const uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x, nwords = (nblk + 31) >> 5;
-    uint32_t r0 = 0u, r1 = 0u, any = 0u;
+    const uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x, nwords = (nblk + 63) >> 6;
+    unsigned long long m[4] = {0ull, 0ull, 0ull, 0ull};
     if (w < nwords) {
-        const u4v lo = reinterpret_cast<const u4v *>(side.wavebits)[2 * w], hi = reinterpret_cast<const u4v *>(side.wavebits)[2 * w + 1];
-        const uint32_t words[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const u4v *src = reinterpret_cast<const u4v *>(side.wavebits) + 4 * w;
 #pragma unroll
-        for (int b = 0; b < 32; ++b) {
-            const uint32_t byte = (w * 32 + b < nblk) ? ((words[b >> 2] >> (8 * (b & 3))) & 0xFFu) : 0u;  // bytes behind the last wave are stale
-            any |= byte;
-            r0 |= ((byte >> 2) & 1u) << b;
-            r1 |= ((byte >> 3) & 1u) << b;
+        for (int q = 0; q < 4; ++q) {
+            const u4v v = src[q];
+            const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const int wave = 16 * q + b;
+                const uint32_t byte = (w * 64 + wave < nblk) ? ((words[b >> 2] >> (8 * (b & 3))) & 0xFFu) : 0u;  // bytes behind the last wave are stale
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[k] |= (unsigned long long)((byte >> k) & 1u) << wave;
+            }
         }
-        side.rbits[0][w] = r0;
-        side.rbits[1][w] = r1;
+        side.occ[0][w] = m[0];
+        side.occ[1][w] = m[1];
+        side.rst[0][w] = m[2];
+        side.rst[1][w] = m[3];
     }
-    const int any2 = __syncthreads_or((int)(any & 1u)), any3 = __syncthreads_or((int)(any & 2u));
+    const int any2 = __syncthreads_or(m[0] != 0ull), any3 = __syncthreads_or(m[1] != 0ull);
     if (threadIdx.x == 0) {
         if (any2) atomicOr(&side.flags[1], 1u);
         if (any3) atomicOr(&side.flags[2], 1u);
     }
 }
 
-// First boundary of opcode X at or after `nominal`: the smallest p >= nominal such that p == 0 or
-// record p - 1 is an X record with the reset bit; n if there is none.  Executed by one full wave.
-__device__ __forceinline__ uint64_t stream_boundary(const uint32_t *tag, const uint32_t *rbits, uint32_t want, uint64_t nominal, uint64_t n,
-                                                    int lane) {
-    if (nominal == 0) return 0;
-    uint64_t i = nominal - 1;  // the next record to examine
-    const uint64_t nblk = (n + 63) >> 6, nwords = (nblk + 31) >> 5;
-    for (;;) {  // every trip advances i by at least one record: terminates
-        if (i >= n) return n;
-        if ((i & 2047u) == 0) {  // on a summary-word boundary: 64 words = 128 Ki records per trip
-            const uint64_t w0 = i >> 11;
-            const uint32_t bits = (w0 + lane < nwords) ? rbits[w0 + lane] : 0u;
-            const unsigned long long m = __ballot(bits != 0u);
-            if (!m) { i += 64ull * 2048ull; continue; }
-            const int wl = __ffsll((long long)m) - 1;
-            const uint32_t first = __shfl(bits, wl);
-            i = ((w0 + wl) * 32 + (__ffs((int)first) - 1)) << 6;  // the first 64-record block holding a reset of X
-        }
-        const uint64_t b0 = i & ~63ull, idx = b0 + lane;
-        const bool p = idx >= i && idx < n && (tag[idx] & 7u) == want;
-        const unsigned long long m = __ballot(p);
-        if (m) return b0 + (uint64_t)(__ffsll((long long)m) - 1) + 1;
-        i = b0 + 64;
-    }
+// A value every lane holds alike, told to the compiler (scalar registers, uniform branches).
+__device__ __forceinline__ unsigned long long wave_uniform(unsigned long long x) {
+    return (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x) |
+           ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32);
 }
 
-constexpr int kFoldThreads = 64;   // one wave per workgroup: the fold is a chain of dependent memory round trips,
-constexpr int kFoldSub = 256;      // so many small workgroups in flight beat few large ones; records per sub-tile
-constexpr int kFoldWaves = kFoldThreads / 64;
-constexpr int kFoldPasses = kFoldSub / kFoldThreads;
+constexpr int kFoldBatch = 8;  // rows in flight per step of the fold
 
+// The fold of one distance opcode; executed by one wave per 64 evaluation waves (see the head of this file).
 template <bool EUC>
-__device__ __forceinline__ void stream_fold(const uint32_t *__restrict__ tag, const float *__restrict__ sum0, const float *__restrict__ sum1,
-                                            const uint32_t *__restrict__ rbits, uint64_t n, uint32_t tile,
-                                            const float *__restrict__ state_in, float *__restrict__ state_out, uint32_t *__restrict__ out) {
-    constexpr uint32_t X = EUC ? 2u : 3u;
-    __shared__ float c_sum0[kFoldSub], c_sum1[EUC ? 1 : kFoldSub], c_out0[kFoldSub], c_out1[EUC ? 1 : kFoldSub];
-    __shared__ uint16_t c_pos[kFoldSub];
-    __shared__ uint8_t c_rs[kFoldSub];
-    __shared__ uint32_t s_cnt[kFoldPasses * kFoldWaves];
-    __shared__ uint64_t s_range[2];
-    __shared__ float s_carry[2][2];
+__device__ __forceinline__ void stream_fold(const StreamSideView &v, uint64_t n, const float *__restrict__ state_in, float *__restrict__ state_out,
+                                            uint32_t *__restrict__ out) {
+    constexpr int X = EUC ? 0 : 1;
+    const int lane = threadIdx.x;
+    const uint64_t nwaves = (n + 63) >> 6, nwords = (nwaves + 63) >> 6;
+    const uint64_t w_end = ((uint64_t)blockIdx.x + 1) * 64;  // the first wave behind the range
+    const unsigned long long *__restrict__ occ = v.occ[X], *__restrict__ rst = v.rst[X];
+    const u4v *__restrict__ heads_of = reinterpret_cast<const u4v *>(v.heads), *__restrict__ tails_of = reinterpret_cast<const u4v *>(v.tails);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = wave; e < 2; e += kFoldWaves) {  // both ends of the range, by different waves where there are two
-        const uint64_t r = stream_boundary(tag, rbits, X | 4u, (uint64_t)(blockIdx.x + e) * tile, n, lane);
-        if (lane == 0) s_range[e] = r;
+    uint64_t j;  // the next wave to look at
+    float c0, c1 = 0.0f;
+    if (blockIdx.x == 0) {  // only the workgroup that starts at record 0 inherits a running sum
+        j = 0;
+        c0 = state_in[0];
+        if (!EUC) c1 = state_in[1];
+    } else {
+        const unsigned long long rs = wave_uniform(rst[blockIdx.x]);
+        if (!rs) return;  // no pair starts behind a wave of this range
+        const uint64_t b = (uint64_t)blockIdx.x * 64 + (uint64_t)(__ffsll((long long)rs) - 1);
+        const u4v t = tails_of[b];
+        c0 = __uint_as_float(EUC ? t.x : t.y);
+        if (!EUC) c1 = __uint_as_float(t.z);
+        j = b + 1;
     }
-    if (tid == 0) {  // only the workgroup that starts at record 0 can inherit a running sum
-        s_carry[0][0] = (blockIdx.x == 0) ? state_in[0] : 0.0f;
-        s_carry[0][1] = (!EUC && blockIdx.x == 0) ? state_in[1] : 0.0f;
-    }
-    __syncthreads();
-    const uint64_t lo = s_range[0], hi = s_range[1];
-    if (lo >= hi) return;
 
-    int par = 0;
-    for (uint64_t base = lo; base < hi; base += kFoldSub) {
-        const int cnt = (hi - base < (uint64_t)kFoldSub) ? (int)(hi - base) : kFoldSub;
-        // compaction of the opcode's beats, in stream order: position p = u * 256 + tid
-        uint32_t tg[kFoldPasses];
-        unsigned long long mk[kFoldPasses];
-#pragma unroll
-        for (int u = 0; u < kFoldPasses; ++u) {
-            const int p = u * kFoldThreads + tid;
-            tg[u] = (p < cnt) ? tag[base + p] : 0xFFu;
-            mk[u] = __ballot((tg[u] & 3u) == X && tg[u] != 0xFFu);
-            if (lane == 0) s_cnt[u * kFoldWaves + wave] = (uint32_t)__popcll(mk[u]);
+    bool done = false;
+    while (j < nwaves && !done) {  // every trip moves j on: terminates
+        const uint64_t blk = j >> 6, base = blk << 6;
+        unsigned long long todo = wave_uniform(occ[blk]) & (~0ull << (j - base));
+        if (!todo) {  // nothing of this opcode in the rest of these 64 waves: look at the next 64 words at once
+            const uint64_t wl = blk + 1 + lane;
+            const unsigned long long far = __ballot(wl < nwords && occ[wl] != 0ull);
+            j = far ? ((blk + 1 + (uint64_t)(__ffsll((long long)far) - 1)) << 6) : ((blk + 65) << 6);
+            continue;
         }
-        __syncthreads();
-        int m = 0;
+        const unsigned long long rs = wave_uniform(rst[blk]);
+        // lane l holds the head lanes and the tails of wave base + l
+        u4v hd = u4v{0u, 0u, 0u, 0u}, tl = u4v{0u, 0u, 0u, 0u};
+        if (base + lane < nwaves && ((todo >> lane) & 1ull)) {
+            hd = heads_of[base + lane];
+            tl = tails_of[base + lane];
+        }
+        const uint32_t my_lo = EUC ? hd.x : hd.z, my_hi = EUC ? hd.y : hd.w;
+        const uint32_t my_t0 = EUC ? tl.x : tl.y, my_t1 = tl.z;
+        while (todo && !done) {
+            int wv[kFoldBatch];
+            float row0[kFoldBatch], row1[kFoldBatch];
 #pragma unroll
-        for (int u = 0; u < kFoldPasses; ++u) {
-            uint32_t before = 0;
-            for (int k = 0; k < u * kFoldWaves + wave; ++k) before += s_cnt[k];
-            const int p = u * kFoldThreads + tid;
-            if ((tg[u] & 3u) == X && tg[u] != 0xFFu) {
-                const uint32_t k = before + (uint32_t)__popcll(mk[u] & ((1ull << lane) - 1ull));
-                c_sum0[k] = sum0[base + p];
-                if (!EUC) c_sum1[k] = sum1[base + p];
-                c_rs[k] = (uint8_t)((tg[u] >> 2) & 3u);  // bit 0: reset, bit 1: the output is already in the record
-                c_pos[k] = (uint16_t)p;
+            for (int k = 0; k < kFoldBatch; ++k) {  // the rows of the next waves that hold beats of the opcode
+                wv[k] = todo ? (__ffsll((long long)todo) - 1) : -1;
+                todo &= todo - 1;
+                const uint64_t idx = (base + (uint64_t)(wv[k] < 0 ? 0 : wv[k])) * 64 + lane;
+                const bool ok = wv[k] >= 0 && idx < n;
+                row0[k] = ok ? v.sum0[idx] : 0.0f;
+                row1[k] = (!EUC && ok) ? v.sum1[idx] : 0.0f;
             }
-        }
-        for (int k = 0; k < kFoldPasses * kFoldWaves; ++k) m += (int)s_cnt[k];
-        __syncthreads();
-        if (m == 0) continue;  // wave-uniform: no beat of this opcode here, the carry stays where it is
-
-        // one lane per vector pair accumulates its beats in order
-        for (int t0 = tid; t0 < m; t0 += kFoldThreads) {
-            const bool starts = (t0 == 0) || ((c_rs[t0 - 1] & 1u) != 0);
-            if (starts) {
-                float acc0 = (t0 == 0) ? s_carry[par][0] : 0.0f;
-                float acc1 = (t0 == 0) ? s_carry[par][1] : 0.0f;
-                int i = t0;
-                bool rs;
-                do {
-                    const float o0 = acc0 + c_sum0[i];
-                    c_out0[i] = canon_nan(o0);
-                    rs = (c_rs[i] & 1u) != 0;
-                    acc0 = rs ? 0.0f : o0;
-                    if (!EUC) {
-                        const float o1 = acc1 + c_sum1[i];
-                        c_out1[i] = canon_nan(o1);
-                        acc1 = rs ? 0.0f : o1;
+#pragma unroll
+            for (int k = 0; k < kFoldBatch; ++k) {
+                if (wv[k] < 0 || done) continue;  // wave-uniform
+                const unsigned long long heads = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)my_lo, wv[k]) |
+                                                 ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)my_hi, wv[k]) << 32);
+                const bool has_reset = (rs >> wv[k]) & 1ull;
+                float res0 = 0.0f, res1 = 0.0f;
+                stream_wave_walk<!EUC>(heads, 0ull, row0[k], row1[k], lane, c0, c1, res0, res1);  // a reset can only be the last head beat
+                if ((heads >> lane) & 1ull) {  // partial-line writes: without nt each one pulls its line into L2 first
+                    uint32_t *rec = out + ((base + (uint64_t)wv[k]) * 64 + lane) * kRecOut;
+                    if (EUC) {
+                        __builtin_nontemporal_store(__float_as_uint(canon_nan(res0)), rec + 16);
+                    } else {
+                        __builtin_nontemporal_store(__float_as_uint(canon_nan(res0)), rec + 18);
+                        __builtin_nontemporal_store(__float_as_uint(canon_nan(res1)), rec + 19);
                     }
-                    ++i;
-                } while (i < m && !rs);
-                if (i == m) {  // exactly one lane reaches the end of the compacted beats
-                    s_carry[par ^ 1][0] = acc0;
-                    s_carry[par ^ 1][1] = acc1;
+                }
+                if (has_reset) {  // behind the wave runs what it counted from its last reset on
+                    c0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)my_t0, wv[k]));
+                    if (!EUC) c1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)my_t1, wv[k]));
+                    if (base + (uint64_t)wv[k] >= w_end) done = true;  // the pairs behind it belong to a later workgroup
                 }
             }
         }
-        __syncthreads();
-        for (int t0 = tid; t0 < m; t0 += kFoldThreads) {  // partial-line writes: without nt each one pulls its line into L2 first
-            if (c_rs[t0] & 2u) continue;  // k_stream_eval wrote this beat's outputs with the record
-            uint32_t *rec = out + (base + c_pos[t0]) * kRecOut;
-            if (EUC) {
-                __builtin_nontemporal_store(__float_as_uint(c_out0[t0]), rec + 16);
-            } else {
-                __builtin_nontemporal_store(__float_as_uint(c_out0[t0]), rec + 18);
-                __builtin_nontemporal_store(__float_as_uint(c_out1[t0]), rec + 19);
-            }
-        }
-        par ^= 1;
-        __syncthreads();
+        j = base + 64;
     }
-    if (hi == n && tid == 0) {  // the workgroup that owns the last record hands the registers on
-        state_out[0] = canon_nan(s_carry[par][0]);
-        if (!EUC) state_out[1] = canon_nan(s_carry[par][1]);
+    if (!done && lane == 0) {  // the workgroup whose walk reaches the last record hands the registers on
+        state_out[0] = canon_nan(c0);
+        if (!EUC) state_out[1] = canon_nan(c1);
     }
 }
 
 // blockIdx.y = 0: Euclidean, 1: angular, side by side in one launch; an opcode that does not occur in
-// the stream (flags written by k_stream_eval) costs one load per workgroup.  state: {euclid, dot, norm}; state_out is
+// the stream (flags written by k_stream_bits) costs one load per workgroup.  state: {euclid, dot, norm}; state_out is
 // written completely: by the workgroup that owns the last record of an opcode that occurs, and as a copy of state_in
 // for an opcode that does not.
-__global__ __launch_bounds__(kFoldThreads) void k_stream_fold(StreamSideView v, uint64_t n, uint32_t tile, const float *__restrict__ state_in,
-                                                     float *__restrict__ state_out, uint32_t *__restrict__ out) {
+__global__ __launch_bounds__(64) void k_stream_fold(StreamSideView v, uint64_t n, const float *__restrict__ state_in, float *__restrict__ state_out,
+                                                    uint32_t *__restrict__ out) {
     if (blockIdx.y == 0) {
-        if (v.flags[1]) stream_fold<true>(v.tag, v.sum0, v.sum1, v.rbits[0], n, tile, state_in, state_out, out);
+        if (v.flags[1]) stream_fold<true>(v, n, state_in, state_out, out);
         else if (blockIdx.x == 0 && threadIdx.x == 0) state_out[0] = state_in[0];
     } else {
-        if (v.flags[2]) stream_fold<false>(v.tag, v.sum0, v.sum1, v.rbits[1], n, tile, state_in + 1, state_out + 1, out);
+        if (v.flags[2]) stream_fold<false>(v, n, state_in + 1, state_out + 1, out);
         else if (blockIdx.x == 0 && threadIdx.x == 0) { state_out[1] = state_in[1]; state_out[2] = state_in[2]; }
     }
 }
@@ -787,50 +767,47 @@ hipError_t stream_chain_eval(const uint32_t *in, uint64_t n, uint64_t capacity, 
     return hipGetLastError();
 }
 
-// Workspace for pieces of at most `capacity` records: tag, sum0, sum1, the two bit arrays, 256 bytes of flags.
-static StreamSide stream_fused_layout(char *workspace, uint64_t capacity, size_t *bits_bytes) {
-    const uint64_t nblk = (capacity + 63) / 64, nwords = (nblk + 31) / 32;
+// Workspace for pieces of at most `capacity` records: the two sum arrays, per wave heads / tails / byte, the four bit arrays, 256 bytes of flags.
+static StreamSide stream_fused_layout(char *workspace, uint64_t capacity) {
+    const uint64_t nblk = (capacity + 63) / 64, nwords = (nblk + 63) / 64;
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     StreamSide side;
     size_t o = 0;
-    side.tag = ws_at<uint32_t>(workspace, o); o += up(capacity * 4);
     side.sum0 = ws_at<float>(workspace, o); o += up(capacity * 4);
     side.sum1 = ws_at<float>(workspace, o); o += up(capacity * 4);
-    side.rbits[0] = ws_at<uint32_t>(workspace, o); o += up(nwords * 4);
-    side.rbits[1] = ws_at<uint32_t>(workspace, o); o += up(nwords * 4);
-    side.wavebits = ws_at<uint8_t>(workspace, o); o += up(nwords * 32);  // whole 32-byte groups: k_stream_bits reads them with 16-byte loads
+    side.heads = ws_at<u4v>(workspace, o); o += up(nblk * 16);
+    side.tails = ws_at<u4v>(workspace, o); o += up(nblk * 16);
+    side.wavebits = ws_at<uint8_t>(workspace, o); o += up(nwords * 64);  // whole 64-byte groups: k_stream_bits reads them with 16-byte loads
+    for (int k = 0; k < 2; ++k) { side.occ[k] = ws_at<unsigned long long>(workspace, o); o += up(nwords * 8); }
+    for (int k = 0; k < 2; ++k) { side.rst[k] = ws_at<unsigned long long>(workspace, o); o += up(nwords * 8); }
     side.flags = ws_at<uint32_t>(workspace, o);
-    if (bits_bytes) *bits_bytes = 2 * up(nwords * 4);
     return side;
 }
 
 size_t stream_fused_workspace(uint64_t capacity) {
-    size_t bits = 0;
-    const StreamSide side = stream_fused_layout(nullptr, capacity, &bits);
+    const StreamSide side = stream_fused_layout(nullptr, capacity);
     return static_cast<size_t>(reinterpret_cast<uintptr_t>(side.flags)) + 256;
 }
 
 // One piece of n <= capacity records.  first_piece: also clears the sticky "opcode > 3" word, once per call.
 hipError_t stream_fused_eval(const uint32_t *in, uint64_t n, uint64_t capacity, int extended, uint32_t *out, char *workspace,
                              StreamSideView *view, hipStream_t s, bool first_piece) {
-    size_t bits = 0;
-    const StreamSide side = stream_fused_layout(workspace, capacity, &bits);
+    const StreamSide side = stream_fused_layout(workspace, capacity);
     const uint64_t nblk = (n + 63) / 64;
     if (n > capacity || nblk > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(side.flags, 0, first_piece ? 256 : 32, s);  // the per-piece flags (all flags on the first piece)
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_stream_eval, dim3((unsigned)nblk), dim3(64), 0, s, in, n, extended, out, side);
-    hipLaunchKernelGGL(k_stream_bits, dim3((unsigned)(((nblk + 31) / 32 + 255) / 256)), dim3(256), 0, s, side, nblk);
-    view->tag = side.tag; view->sum0 = side.sum0; view->sum1 = side.sum1;
-    view->rbits[0] = side.rbits[0]; view->rbits[1] = side.rbits[1]; view->flags = side.flags;
+    if (extended) hipLaunchKernelGGL(k_stream_bits, dim3((unsigned)(((nblk + 63) / 64 + 255) / 256)), dim3(256), 0, s, side, nblk);
+    view->sum0 = side.sum0; view->sum1 = side.sum1; view->heads = side.heads; view->tails = side.tails;
+    view->occ[0] = side.occ[0]; view->occ[1] = side.occ[1]; view->rst[0] = side.rst[0]; view->rst[1] = side.rst[1]; view->flags = side.flags;
     return hipGetLastError();
 }
 
 hipError_t stream_fused_fold(const StreamSideView &v, uint64_t n, const float *state_in, float *state_out, uint32_t *out, hipStream_t s) {
-    const uint32_t tile = kFoldSub;
-    const uint64_t blocks = (n + tile - 1) / tile;
+    const uint64_t blocks = ((n + 63) / 64 + 63) / 64;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_stream_fold, dim3((unsigned)blocks, 2), dim3(kFoldThreads), 0, s, v, n, tile, state_in, state_out, out);
+    hipLaunchKernelGGL(k_stream_fold, dim3((unsigned)blocks, 2), dim3(64), 0, s, v, n, state_in, state_out, out);
     return hipGetLastError();
 }
 
