@@ -868,7 +868,7 @@ static int bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt_dp_
         // ONE pass over the records: every wave evaluates its 64 records and adds up its distance beats in stream order,
         // the running sums travel from wave to wave (stream_fused.hip: k_stream_chain).  Pieces of 2^26 records bound
         // the workspace (24 bytes per 64 records of a piece).  Same bits as the two-pass form below, but slower on
-        // MI355X (7.6 against 11.4 G records/s at 2^24 records: the look-back is one more memory round trip in the life
+        // MI355X (7.6 against 13.4 G records/s at 2^24 records: the look-back is one more memory round trip in the life
         // of a wave, and only 7 waves fit a CU next to their 21 KiB of staged records), so it is never chosen by itself.
         const int lg = env_int("RT_DP_STREAM_CHUNK_LOG2", 26);
         const uint64_t chunk = 1ull << (lg < 11 ? 11 : (lg > 30 ? 30 : lg));
@@ -929,7 +929,7 @@ static int bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt_dp_
     }
     if (ctx->stream_mode == 2 || (ctx->stream_mode == 0 && aligned16)) {
         // one pass over the records: evaluate in place, then add up the distance beats in stream order
-        // in pieces of 2^26 records, which bounds the workspace (12 bytes per record of a piece); smaller pieces
+        // in pieces of 2^26 records, which bounds the workspace (12.6 bytes per record of a piece); smaller pieces
         // measured slower (2^20: -17 %), the per-piece launches cost more than cache residency returns
         const int lg = env_int("RT_DP_STREAM_CHUNK_LOG2", 26);
         const uint64_t chunk = 1ull << (lg < 11 ? 11 : (lg > 30 ? 30 : lg));

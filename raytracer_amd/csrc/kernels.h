@@ -101,10 +101,10 @@ hipError_t launch_knn_euclid16(const float *pts, uint32_t n_pts, const float *qr
                                uint32_t splits, bool angular, float *out_d, uint32_t *out_i, hipStream_t stream);
 // fused record-stream path (stream_fused.hip)
 struct StreamSideView {
-    const float *sum0, *sum1;
+    const float *hs[3];
     const void *heads, *tails;              // 16 bytes per evaluation wave each
     const unsigned long long *occ[2], *rst[2];
-    const uint32_t *flags;  // [1] opcode 2 present, [2] opcode 3 present (per launch); [8] opcode > 3 seen (sticky, cleared by the caller)
+    const uint32_t *flags;  // per launch: [1] opcode 2 present, [2] opcode 3 present, [4] / [5] 1 + the last wave holding one; [8] opcode > 3 seen (sticky, cleared by the caller)
 };
 size_t stream_fused_workspace(uint64_t capacity);
 hipError_t stream_fused_eval(const uint32_t *in, uint64_t n, uint64_t capacity, int extended, uint32_t *out, char *workspace,

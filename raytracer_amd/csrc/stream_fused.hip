@@ -18,20 +18,24 @@
 //                   reset; all of them when it holds no reset): they continue a pair from an
 //                   earlier wave.  The 21-word output records go back through LDS to coalesced
 //                   stores.  Per wave and distance opcode the side arrays receive the head
-//                   lanes as a 64-bit mask, the TAIL sum (the running sum behind the wave's last
-//                   record, counted from its last reset), the beats' tree sums as rows of 64,
-//                   and one byte saying which distance opcodes occur with / without a reset.
-//   k_stream_bits   turns the bytes into one bit per wave (64 waves per word) and the
-//                   "opcode occurs" flags.
-//   k_stream_fold   per distance opcode: a workgroup of one wave is in charge of the pairs that
-//                   run out of the 64 evaluation waves of its range, i.e. of every head beat
-//                   behind the first reset-holding wave of the range up to and including the
-//                   heads of the first reset-holding wave behind the range.  It walks those
-//                   waves in order (rows are fetched eight waves at a time, the walk itself
-//                   runs in registers), re-seeds the running sum with the tail of every
-//                   reset-holding wave it passes, and patches the results into the output
-//                   records.  Waves without a beat of the opcode are skipped through the bit
-//                   words, 256 Ki records per step where there are none for long.
+//                   lanes as a 64-bit mask, the head beats' tree sums in stream order (a row
+//                   of 64 per wave, filled from its start), the TAIL sum (the running sum
+//                   behind the wave's last record, counted from its last reset), and one byte
+//                   saying which distance opcodes occur with / without a reset.
+//   k_stream_bits   turns the bytes into one bit per wave (64 waves per word), the "opcode
+//                   occurs" flags and the index of the last wave that holds the opcode.
+//   k_stream_fold   per distance opcode, one fold wave per 64 evaluation waves, one LANE per
+//                   evaluation wave.  The sum that runs into a wave is known without any walk
+//                   when the nearest wave in front of it that holds the opcode also holds a
+//                   reset: it is that wave's tail (the registers entering the stream, in front
+//                   of the first one).  Every such wave's head beats are added up by its lane
+//                   and patched into the output records: two memory round trips in the common
+//                   case, whatever the stream's length.  A wave WITHOUT a reset hands its sum on:
+//                   the waves behind it are then walked in order by the whole fold wave (rows
+//                   fetched eight waves at a time, the walk itself in registers) up to and
+//                   including the next wave that holds a reset; waves without the opcode are
+//                   skipped through the bit words, 256 Ki records per step.  Whoever handles the
+//                   last wave that holds the opcode writes the registers behind the stream.
 // Output fields of foreign opcodes are zero and the two *_reset_accum fields echo the input
 // bit for every opcode (:1205, :1254, :1267-1268).
 #include "ops.hpp"
@@ -45,14 +49,15 @@ constexpr int kRecOut = 21;   // words per rt_dp_output_bundle
 constexpr int kWaveRecs = 64;
 
 struct StreamSide {
-    float *sum0, *sum1;            // [n]   tree sums of a distance beat (Euclidean: sum0; angular: dot, norm); a wave's row of sum0 is written
-                                   //       when it holds head beats, its row of sum1 when it holds angular head beats
+    float *hs[3];                  // [64 * ceil(n / 64)] each: per wave a row of 64 with the tree sums of its head beats in stream order from
+                                   //       the row's start: Euclidean sums, angular dots, angular norms
     u4v *heads;                    // [ceil(n / 64)] per wave: head lanes of opcode 2 (x, y = low, high half), of opcode 3 (z, w)
     u4v *tails;                    // [ceil(n / 64)] per wave: tail sums {Euclidean, angular dot, angular norm, unused}; valid where the wave holds a reset
     uint8_t *wavebits;             // [ceil(n / 64)] per wave: 1 / 2 = a beat of opcode 2 / 3 occurs, 4 / 8 = one with its reset bit
     unsigned long long *occ[2];    // [ceil(n / 4096)] bit b of word w: wave 64 w + b holds a beat of opcode 2 / 3
     unsigned long long *rst[2];    // likewise: ... holds one with its reset bit
-    uint32_t *flags;               // [1] opcode 2 present, [2] opcode 3 present (per launch); [8] an opcode > 3 was seen (sticky)
+    uint32_t *flags;               // per launch: [1] opcode 2 present, [2] opcode 3 present, [4] / [5] 1 + the last wave that holds a beat of
+                                   // opcode 2 / 3; [8] an opcode > 3 was seen (sticky)
 };
 
 __device__ __forceinline__ float tree16(const float (&s)[16]) {  // (i, i+8), (i, i+4), (i, i+2), (0, 1)
@@ -371,8 +376,13 @@ __global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__
             stream_wave_walk<true>(rest, r3, sum0, sum1, lane, tail_d, tail_n, res0, res1);
             if ((rest >> lane) & 1ull) { w[18] = __float_as_uint(canon_nan(res0)); w[19] = __float_as_uint(canon_nan(res1)); }
         }
-        if (have && (h2 | h3)) side.sum0[r0 + lane] = sum0;
-        if (have && h3) side.sum1[r0 + lane] = sum1;
+        const unsigned long long lower = (1ull << lane) - 1ull;
+        if ((h2 >> lane) & 1ull) side.hs[0][r0 + __popcll(h2 & lower)] = sum0;
+        if ((h3 >> lane) & 1ull) {
+            const int k = __popcll(h3 & lower);
+            side.hs[1][r0 + k] = sum0;
+            side.hs[2][r0 + k] = sum1;
+        }
         // What the fold needs to know about this wave: plain stores, no atomic and no device-scope read in the life of a
         // wave (an earlier form set summary bits and launch flags with atomics guarded by a device-scope load of the flag:
         // one more memory round trip per wave).
@@ -422,10 +432,16 @@ __global__ __launch_bounds__(256) void k_stream_bits(StreamSide side, uint64_t n
         side.rst[0][w] = m[2];
         side.rst[1][w] = m[3];
     }
-    const int any2 = __syncthreads_or(m[0] != 0ull), any3 = __syncthreads_or(m[1] != 0ull);
-    if (threadIdx.x == 0) {
-        if (any2) atomicOr(&side.flags[1], 1u);
-        if (any3) atomicOr(&side.flags[2], 1u);
+    __shared__ uint32_t s_last[2];
+    if (threadIdx.x < 2) s_last[threadIdx.x] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (m[k]) atomicMax(&s_last[k], (uint32_t)(w * 64 + (uint64_t)(63 - __builtin_clzll(m[k])) + 1u));
+    __syncthreads();
+    if (threadIdx.x < 2 && s_last[threadIdx.x]) {
+        atomicOr(&side.flags[1 + threadIdx.x], 1u);
+        atomicMax(&side.flags[4 + threadIdx.x], s_last[threadIdx.x]);
     }
 }
 
@@ -435,37 +451,22 @@ __device__ __forceinline__ unsigned long long wave_uniform(unsigned long long x)
            ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32);
 }
 
-constexpr int kFoldBatch = 8;  // rows in flight per step of the fold
+constexpr int kFoldBatch = 8;  // rows in flight per step of a chain walk
 
-// The fold of one distance opcode; executed by one wave per 64 evaluation waves (see the head of this file).
+__device__ __forceinline__ float pick4(const f4v &q, int i) { return i == 0 ? q.x : i == 1 ? q.y : i == 2 ? q.z : q.w; }
+
+// A pair that runs through whole waves: entered with the running sum c0 / c1 behind a wave without a reset, the waves from j on
+// are walked one after the other by the whole wave (the sum is wave-uniform) up to and including the first one that holds a
+// reset, or the last one that holds a beat of the opcode at all, which is where the registers behind the stream come from.
 template <bool EUC>
-__device__ __forceinline__ void stream_fold(const StreamSideView &v, uint64_t n, const float *__restrict__ state_in, float *__restrict__ state_out,
-                                            uint32_t *__restrict__ out) {
+__device__ __forceinline__ void stream_fold_chain(const StreamSideView &v, uint64_t nwords, uint64_t j, float c0, float c1, uint64_t last,
+                                                  float *__restrict__ state_out, uint32_t *__restrict__ out) {
     constexpr int X = EUC ? 0 : 1;
     const int lane = threadIdx.x;
-    const uint64_t nwaves = (n + 63) >> 6, nwords = (nwaves + 63) >> 6;
-    const uint64_t w_end = ((uint64_t)blockIdx.x + 1) * 64;  // the first wave behind the range
     const unsigned long long *__restrict__ occ = v.occ[X], *__restrict__ rst = v.rst[X];
     const u4v *__restrict__ heads_of = reinterpret_cast<const u4v *>(v.heads), *__restrict__ tails_of = reinterpret_cast<const u4v *>(v.tails);
-
-    uint64_t j;  // the next wave to look at
-    float c0, c1 = 0.0f;
-    if (blockIdx.x == 0) {  // only the workgroup that starts at record 0 inherits a running sum
-        j = 0;
-        c0 = state_in[0];
-        if (!EUC) c1 = state_in[1];
-    } else {
-        const unsigned long long rs = wave_uniform(rst[blockIdx.x]);
-        if (!rs) return;  // no pair starts behind a wave of this range
-        const uint64_t b = (uint64_t)blockIdx.x * 64 + (uint64_t)(__ffsll((long long)rs) - 1);
-        const u4v t = tails_of[b];
-        c0 = __uint_as_float(EUC ? t.x : t.y);
-        if (!EUC) c1 = __uint_as_float(t.z);
-        j = b + 1;
-    }
-
-    bool done = false;
-    while (j < nwaves && !done) {  // every trip moves j on: terminates
+    const float *__restrict__ hs0 = v.hs[EUC ? 0 : 1], *__restrict__ hs1 = v.hs[2];
+    while (j <= last) {  // every trip moves j on: terminates
         const uint64_t blk = j >> 6, base = blk << 6;
         unsigned long long todo = wave_uniform(occ[blk]) & (~0ull << (j - base));
         if (!todo) {  // nothing of this opcode in the rest of these 64 waves: look at the next 64 words at once
@@ -475,35 +476,49 @@ __device__ __forceinline__ void stream_fold(const StreamSideView &v, uint64_t n,
             continue;
         }
         const unsigned long long rs = wave_uniform(rst[blk]);
-        // lane l holds the head lanes and the tails of wave base + l
-        u4v hd = u4v{0u, 0u, 0u, 0u}, tl = u4v{0u, 0u, 0u, 0u};
-        if (base + lane < nwaves && ((todo >> lane) & 1ull)) {
+        bool ends = false;
+        if (rs & todo) {
+            const int sw = __ffsll((long long)(rs & todo)) - 1;
+            todo &= (sw == 63) ? ~0ull : ((2ull << sw) - 1ull);
+            ends = true;
+        }
+        const int top = 63 - __builtin_clzll(todo);
+        u4v hd = u4v{0u, 0u, 0u, 0u}, tl = u4v{0u, 0u, 0u, 0u};  // lane l: the head lanes and the tails of wave base + l
+        if ((todo >> lane) & 1ull) {
             hd = heads_of[base + lane];
             tl = tails_of[base + lane];
         }
         const uint32_t my_lo = EUC ? hd.x : hd.z, my_hi = EUC ? hd.y : hd.w;
         const uint32_t my_t0 = EUC ? tl.x : tl.y, my_t1 = tl.z;
-        while (todo && !done) {
+        while (todo) {
             int wv[kFoldBatch];
             float row0[kFoldBatch], row1[kFoldBatch];
 #pragma unroll
-            for (int k = 0; k < kFoldBatch; ++k) {  // the rows of the next waves that hold beats of the opcode
+            for (int k = 0; k < kFoldBatch; ++k) {  // the rows of the next waves that hold beats of the opcode (whole rows exist, their ends are stale)
                 wv[k] = todo ? (__ffsll((long long)todo) - 1) : -1;
                 todo &= todo - 1;
                 const uint64_t idx = (base + (uint64_t)(wv[k] < 0 ? 0 : wv[k])) * 64 + lane;
-                const bool ok = wv[k] >= 0 && idx < n;
-                row0[k] = ok ? v.sum0[idx] : 0.0f;
-                row1[k] = (!EUC && ok) ? v.sum1[idx] : 0.0f;
+                row0[k] = (wv[k] >= 0) ? hs0[idx] : 0.0f;
+                row1[k] = (!EUC && wv[k] >= 0) ? hs1[idx] : 0.0f;
             }
 #pragma unroll
             for (int k = 0; k < kFoldBatch; ++k) {
-                if (wv[k] < 0 || done) continue;  // wave-uniform
-                const unsigned long long heads = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)my_lo, wv[k]) |
-                                                 ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)my_hi, wv[k]) << 32);
-                const bool has_reset = (rs >> wv[k]) & 1ull;
+                if (wv[k] < 0) continue;  // wave-uniform
+                unsigned long long heads = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)my_lo, wv[k]) |
+                                           ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)my_hi, wv[k]) << 32);
+                const unsigned long long mask = heads;
                 float res0 = 0.0f, res1 = 0.0f;
-                stream_wave_walk<!EUC>(heads, 0ull, row0[k], row1[k], lane, c0, c1, res0, res1);  // a reset can only be the last head beat
-                if ((heads >> lane) & 1ull) {  // partial-line writes: without nt each one pulls its line into L2 first
+                for (int r = 0; heads; ++r) {  // the r-th head beat sits in lane L of its wave; its sum is the r-th of the row
+                    const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)heads) - 1);
+                    heads &= heads - 1;
+                    c0 = c0 + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row0[k]), r));
+                    if (lane == L) res0 = c0;
+                    if (!EUC) {
+                        c1 = c1 + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row1[k]), r));
+                        if (lane == L) res1 = c1;
+                    }
+                }
+                if ((mask >> lane) & 1ull) {  // partial-line writes: without nt each one pulls its line into L2 first
                     uint32_t *rec = out + ((base + (uint64_t)wv[k]) * 64 + lane) * kRecOut;
                     if (EUC) {
                         __builtin_nontemporal_store(__float_as_uint(canon_nan(res0)), rec + 16);
@@ -512,18 +527,119 @@ __device__ __forceinline__ void stream_fold(const StreamSideView &v, uint64_t n,
                         __builtin_nontemporal_store(__float_as_uint(canon_nan(res1)), rec + 19);
                     }
                 }
-                if (has_reset) {  // behind the wave runs what it counted from its last reset on
-                    c0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)my_t0, wv[k]));
-                    if (!EUC) c1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)my_t1, wv[k]));
-                    if (base + (uint64_t)wv[k] >= w_end) done = true;  // the pairs behind it belong to a later workgroup
-                }
             }
         }
+        if (ends) {  // behind a reset-holding wave runs what it counted from its last reset on
+            c0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)my_t0, top));
+            if (!EUC) c1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)my_t1, top));
+        }
+        if (base + (uint64_t)top == last) {
+            if (lane == 0) {
+                state_out[0] = canon_nan(c0);
+                if (!EUC) state_out[1] = canon_nan(c1);
+            }
+            return;
+        }
+        if (ends) return;
         j = base + 64;
     }
-    if (!done && lane == 0) {  // the workgroup whose walk reaches the last record hands the registers on
-        state_out[0] = canon_nan(c0);
-        if (!EUC) state_out[1] = canon_nan(c1);
+}
+
+// The fold of one distance opcode; executed by one wave per 64 evaluation waves (see the head of this file).
+template <bool EUC>
+__device__ __forceinline__ void stream_fold(const StreamSideView &v, uint64_t n, const float *__restrict__ state_in, float *__restrict__ state_out,
+                                            uint32_t *__restrict__ out) {
+    constexpr int X = EUC ? 0 : 1;
+    const int lane = threadIdx.x;
+    const uint64_t nwaves = (n + 63) >> 6, nwords = (nwaves + 63) >> 6;
+    const uint64_t g = blockIdx.x, base = g << 6;
+    const unsigned long long *__restrict__ occ = v.occ[X], *__restrict__ rst = v.rst[X];
+    const u4v *__restrict__ heads_of = reinterpret_cast<const u4v *>(v.heads), *__restrict__ tails_of = reinterpret_cast<const u4v *>(v.tails);
+    const float *__restrict__ hs0 = v.hs[EUC ? 0 : 1], *__restrict__ hs1 = v.hs[2];
+
+    const unsigned long long occw = wave_uniform(occ[g]), rstw = wave_uniform(rst[g]);
+    const uint64_t last = (uint64_t)v.flags[4 + X] - 1u;  // the caller has seen that the opcode occurs
+    // The wave that holds a beat of the opcode nearest in front of this range, and whether it holds a reset; lane l looks at word g - 1 - l.
+    long long pw = -1;
+    bool pr = true;  // in front of the stream: the registers that enter it count as the tail of a reset-holding wave
+    {
+        uint64_t w = g;
+        while (w > 0) {  // 64 words per trip
+            const long long wi = (long long)w - 1 - lane;
+            const unsigned long long o = (wi >= 0) ? occ[wi] : 0ull, r = (wi >= 0) ? rst[wi] : 0ull;
+            const unsigned long long any = __ballot(o != 0ull);
+            if (!any) { w = (w > 64) ? w - 64 : 0; continue; }
+            const int L = __ffsll((long long)any) - 1;
+            const unsigned long long ow = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o, L) |
+                                          ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o >> 32), L) << 32);
+            const unsigned long long rw = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)r, L) |
+                                          ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(r >> 32), L) << 32);
+            const int bit = 63 - __builtin_clzll(ow);
+            pw = (long long)((w - 1 - (uint64_t)L) * 64 + (uint64_t)bit);
+            pr = (rw >> bit) & 1ull;
+            break;
+        }
+    }
+    if (!occw) return;  // no beat of the opcode in this range: pairs that pass through it are walked by whoever started them
+
+    // Lane l stands for wave base + l.  The sum that runs into a wave is known without walking when the nearest wave in front of
+    // it that holds a beat of the opcode also holds a reset: it is that wave's tail.  One lane per such wave walks its head beats.
+    const bool mine = (occw >> lane) & 1ull;
+    const uint64_t row = (base + lane) * 64;
+    u4v hd = u4v{0u, 0u, 0u, 0u}, tl = u4v{0u, 0u, 0u, 0u};
+    f4v q0 = f4v{0.0f, 0.0f, 0.0f, 0.0f}, q1 = q0;
+    if (mine) {
+        hd = heads_of[base + lane];
+        tl = tails_of[base + lane];
+        q0 = *reinterpret_cast<const f4v *>(hs0 + row);  // the first four head beats' sums; most waves hold no more
+        if (!EUC) q1 = *reinterpret_cast<const f4v *>(hs1 + row);
+    }
+    float f0 = 0.0f, f1 = 0.0f;  // what runs into the first wave of the range that holds a beat, if that is known
+    if (pw < 0) {
+        f0 = state_in[0];
+        if (!EUC) f1 = state_in[1];
+    } else if (pr) {
+        const u4v t = tails_of[pw];
+        f0 = __uint_as_float(EUC ? t.x : t.y);
+        f1 = __uint_as_float(t.z);
+    }
+    const uint32_t my_t0 = EUC ? tl.x : tl.y, my_t1 = tl.z;
+    const unsigned long long below = occw & ((1ull << lane) - 1ull);
+    const int prev = below ? (63 - __builtin_clzll(below)) : 0;
+    const float p0 = __uint_as_float((uint32_t)__shfl((int)my_t0, prev)), p1 = __uint_as_float((uint32_t)__shfl((int)my_t1, prev));
+    const bool known = mine && (below ? (((rstw >> prev) & 1ull) != 0) : pr);
+    const bool resets = (rstw >> lane) & 1ull;
+    float acc0 = below ? p0 : f0, acc1 = below ? p1 : f1;
+    unsigned long long m = known ? ((unsigned long long)(EUC ? hd.x : hd.z) | ((unsigned long long)(EUC ? hd.y : hd.w) << 32)) : 0ull;
+    for (int r = 0; m; ++r) {
+        if (r && !(r & 3)) {  // the next four
+            q0 = *reinterpret_cast<const f4v *>(hs0 + row + r);
+            if (!EUC) q1 = *reinterpret_cast<const f4v *>(hs1 + row + r);
+        }
+        const int bt = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        uint32_t *rec = out + (row + bt) * kRecOut;
+        acc0 = acc0 + pick4(q0, r & 3);
+        if (EUC) {
+            __builtin_nontemporal_store(__float_as_uint(canon_nan(acc0)), rec + 16);  // partial-line writes: without nt each one pulls its line into L2 first
+        } else {
+            acc1 = acc1 + pick4(q1, r & 3);
+            __builtin_nontemporal_store(__float_as_uint(canon_nan(acc0)), rec + 18);
+            __builtin_nontemporal_store(__float_as_uint(canon_nan(acc1)), rec + 19);
+        }
+    }
+    if (known && base + lane == last) {  // the registers behind the stream
+        state_out[0] = canon_nan(resets ? __uint_as_float(my_t0) : acc0);
+        if (!EUC) state_out[1] = canon_nan(resets ? __uint_as_float(my_t1) : acc1);
+    }
+    // Waves without a reset hand their sum on to the waves behind them: those are walked in order, starting here.
+    unsigned long long chains = __ballot(known && !resets && base + lane != last);
+    while (chains) {
+        const int p = __ffsll((long long)chains) - 1;
+        chains &= chains - 1;
+        const float c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc0), p));
+        const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc1), p));
+        stream_fold_chain<EUC>(v, nwords, base + (uint64_t)p + 1, c0, c1, last, state_out, out);
     }
 }
 
@@ -773,8 +889,7 @@ static StreamSide stream_fused_layout(char *workspace, uint64_t capacity) {
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     StreamSide side;
     size_t o = 0;
-    side.sum0 = ws_at<float>(workspace, o); o += up(capacity * 4);
-    side.sum1 = ws_at<float>(workspace, o); o += up(capacity * 4);
+    for (int k = 0; k < 3; ++k) { side.hs[k] = ws_at<float>(workspace, o); o += up(nblk * 64 * 4); }
     side.heads = ws_at<u4v>(workspace, o); o += up(nblk * 16);
     side.tails = ws_at<u4v>(workspace, o); o += up(nblk * 16);
     side.wavebits = ws_at<uint8_t>(workspace, o); o += up(nwords * 64);  // whole 64-byte groups: k_stream_bits reads them with 16-byte loads
@@ -799,7 +914,7 @@ hipError_t stream_fused_eval(const uint32_t *in, uint64_t n, uint64_t capacity, 
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_stream_eval, dim3((unsigned)nblk), dim3(64), 0, s, in, n, extended, out, side);
     if (extended) hipLaunchKernelGGL(k_stream_bits, dim3((unsigned)(((nblk + 63) / 64 + 255) / 256)), dim3(256), 0, s, side, nblk);
-    view->sum0 = side.sum0; view->sum1 = side.sum1; view->heads = side.heads; view->tails = side.tails;
+    view->hs[0] = side.hs[0]; view->hs[1] = side.hs[1]; view->hs[2] = side.hs[2]; view->heads = side.heads; view->tails = side.tails;
     view->occ[0] = side.occ[0]; view->occ[1] = side.occ[1]; view->rst[0] = side.rst[0]; view->rst[1] = side.rst[1]; view->flags = side.flags;
     return hipGetLastError();
 }
