@@ -76,101 +76,6 @@ __device__ __forceinline__ float tree8(const float (&s)[8]) {  // (i, i+4), (i, 
     return (t[0] + t[2]) + (t[1] + t[3]);
 }
 
-// One lane evaluates the record it owns (s_rec + 84 * lane): Quadbox and triangle ops completely, for a distance beat the
-// tree sum(s) of the beat, which do not depend on the accumulator.  w: the 21 output words (accumulator fields still 0).
-// Returns false when the opcode is not one of the four.
-__device__ __forceinline__ bool stream_eval_record(const uint32_t *s_rec, int lane, bool have, int extended, uint32_t (&w)[kRecOut], uint32_t &op,
-                                                   uint32_t &reset, float &sum0, float &sum1) {
-    bool known = true;
-    // 16-byte LDS reads of the own record: 21 is odd, so the lanes of a read spread over all banks
-    const u4v *rc = reinterpret_cast<const u4v *>(s_rec + lane * kRecIn);
-    const u4v c0 = rc[0];
-    op = have ? c0.x : 0xFFFFFFFFu;
-    reset = have ? (rc[20].w & 1u) : 0u;
-#pragma unroll
-    for (int k = 0; k < kRecOut; ++k) w[k] = 0u;
-    sum0 = 0.0f;
-    sum1 = 0.0f;
-    if (have) {
-        w[0] = op;
-        if (extended) { w[17] = reset; w[20] = reset; }
-    }
-    if (op == 1u) {  // Quadbox: words 1..10 (ray) and 17..40 (four AABBs)
-        uint32_t W[44];
-        W[1] = c0.y; W[2] = c0.z; W[3] = c0.w;
-#pragma unroll
-        for (int c = 1; c <= 10; ++c) {
-            if (c == 3) continue;
-            const u4v v = rc[c];
-            W[4 * c] = v.x; W[4 * c + 1] = v.y; W[4 * c + 2] = v.z; W[4 * c + 3] = v.w;
-        }
-        float r[kBoxFields], t[4];
-#pragma unroll
-        for (int f = 0; f < 10; ++f) r[f] = __uint_as_float(W[1 + f]);
-#pragma unroll
-        for (int f = 0; f < 24; ++f) r[10 + f] = __uint_as_float(W[17 + f]);
-        uint32_t fl;
-        box_one(r, t, fl);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            w[1 + k] = __float_as_uint(t[k]);
-            w[5 + k] = (fl >> k) & 1u;
-            w[9 + k] = (fl >> (4 + 2 * k)) & 3u;
-        }
-    } else if (op == 0u) {  // Triangle: words 1..3 origin, 11..13 k, 14..16 shear, 41..49 vertices
-        const u4v c2 = rc[2], c3 = rc[3], c4 = rc[4], c10 = rc[10], c11 = rc[11], c12 = rc[12];
-        float r[kTriFields];
-        r[0] = __uint_as_float(c0.y); r[1] = __uint_as_float(c0.z); r[2] = __uint_as_float(c0.w);
-        r[3] = __uint_as_float(c3.z); r[4] = __uint_as_float(c3.w); r[5] = __uint_as_float(c4.x);
-        r[6] = __uint_as_float(c10.y); r[7] = __uint_as_float(c10.z); r[8] = __uint_as_float(c10.w);
-        r[9] = __uint_as_float(c11.x); r[10] = __uint_as_float(c11.y); r[11] = __uint_as_float(c11.z); r[12] = __uint_as_float(c11.w);
-        r[13] = __uint_as_float(c12.x); r[14] = __uint_as_float(c12.y);
-        const uint32_t kw = (c2.w & 3u) | ((c3.x & 3u) << 2) | ((c3.y & 3u) << 4);
-        float num, den;
-        uint32_t hit;
-        tri_one(r, kw, num, den, hit);
-        w[13] = __float_as_uint(num);
-        w[14] = __float_as_uint(den);
-        w[15] = hit;
-    } else if (op == 2u) {  // Euclidean beat: a = words 50..65, b = 66..81, mask = word 82
-        uint32_t W[36];  // words 48..83
-#pragma unroll
-        for (int c = 12; c <= 20; ++c) {
-            const u4v v = rc[c];
-            W[4 * (c - 12)] = v.x; W[4 * (c - 12) + 1] = v.y; W[4 * (c - 12) + 2] = v.z; W[4 * (c - 12) + 3] = v.w;
-        }
-        const uint32_t mask = W[34];
-        float s[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const bool on = (mask >> i) & 1u;
-            const float d = on ? (__uint_as_float(W[2 + i]) - __uint_as_float(W[18 + i])) : 0.0f;  // :221-245
-            s[i] = d * d;                                                                            // :399-419
-        }
-        sum0 = tree16(s);
-    } else if (op == 3u) {  // Angular beat: query = words 50..57, candidate = 66..73
-        const u4v c12 = rc[12], c13 = rc[13], c14 = rc[14], c16 = rc[16], c17 = rc[17], c18 = rc[18], c20 = rc[20];
-        const uint32_t A[8] = {c12.z, c12.w, c13.x, c13.y, c13.z, c13.w, c14.x, c14.y};
-        const uint32_t B[8] = {c16.z, c16.w, c17.x, c17.y, c17.z, c17.w, c18.x, c18.y};
-        const uint32_t mask = c20.z;
-        float s[8], m[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const bool on = (mask >> i) & 1u;
-            const float q = on ? __uint_as_float(A[i]) : 0.0f;  // :246-268
-            const float c = on ? __uint_as_float(B[i]) : 0.0f;
-            s[i] = q * c;                                        // :420-453
-            m[i] = c * c;
-        }
-        sum0 = tree8(s);
-        sum1 = tree8(m);
-    } else if (have) {
-        known = false;  // cannot occur in the RTL's 2-bit field
-    }
-    return known;
-}
-
-
 // The X beats selected by `todo` (a subset of the wave's lanes, ascending = stream order) are added onto acc one by one;
 // the owning lane keeps its beat's result in res; a beat with its reset bit restarts the sum from +0 behind it.
 template <bool TWO>
@@ -304,14 +209,8 @@ __device__ __forceinline__ bool stream_eval_compact(const u4v *rc, uint32_t op_i
     return known;
 }
 
-__global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__ in, uint64_t n, int extended, uint32_t *__restrict__ out,
-                                                    StreamSide side) {
-    __shared__ __align__(16) uint32_t s_rec[kWaveRecs * kLiveStride * 4];  // 11 KiB of live chunks; re-used for the output records (5.25 KiB)
-    __shared__ uint32_t s_op[kWaveRecs];
-    const int lane = threadIdx.x;
-    const uint64_t r0 = (uint64_t)blockIdx.x * kWaveRecs;
-    const uint32_t live = (n - r0 < (uint64_t)kWaveRecs) ? (uint32_t)(n - r0) : (uint32_t)kWaveRecs;
-
+// The wave's records from HBM into the compact rows of s_rec (11 slots of 16 bytes per record) and their opcodes into s_op.
+__device__ __forceinline__ void stream_stage(const uint32_t *__restrict__ in, uint64_t r0, uint32_t live, int lane, uint32_t *s_rec, uint32_t *s_op) {
     // Coalesced loads of the wave's whole records (chunk g = j * 64 + lane of its 21 KiB); fetching only the chunks a record's
     // opcode reads measured 9-11 % slower on MI355X -- the lines come in full anyway.  Chunk g belongs to record g / 21; 64 = 3 * 21 + 1,
     // so from one load to the next a lane moves three records on and one chunk up (four records on where the chunk wraps).
@@ -345,6 +244,17 @@ __global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__
         }
     }
     __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__ in, uint64_t n, int extended, uint32_t *__restrict__ out,
+                                                    StreamSide side) {
+    __shared__ __align__(16) uint32_t s_rec[kWaveRecs * kLiveStride * 4];  // 11 KiB of live chunks; re-used for the output records (5.25 KiB)
+    __shared__ uint32_t s_op[kWaveRecs];
+    const int lane = threadIdx.x;
+    const uint64_t r0 = (uint64_t)blockIdx.x * kWaveRecs;
+    const uint32_t live = (n - r0 < (uint64_t)kWaveRecs) ? (uint32_t)(n - r0) : (uint32_t)kWaveRecs;
+
+    stream_stage(in, r0, live, lane, s_rec, s_op);
 
     const bool have = (uint32_t)lane < live;
     uint32_t w[kRecOut], op, reset;
@@ -764,27 +674,16 @@ __device__ __forceinline__ void stream_wave_fold(unsigned long long e, unsigned 
 
 __global__ __launch_bounds__(64) void k_stream_chain(const uint32_t *__restrict__ in, uint64_t n, int extended, uint32_t *__restrict__ out,
                                                      StreamChain ch, const float *__restrict__ state_in, int mute) {
-    __shared__ __align__(16) uint32_t s_rec[kWaveRecs * kRecIn];  // 21 KiB; re-used for the output records
+    __shared__ __align__(16) uint32_t s_rec[kWaveRecs * kLiveStride * 4];  // 11 KiB of live chunks; re-used for the output records
+    __shared__ uint32_t s_op[kWaveRecs];
     const int lane = threadIdx.x;
     const uint64_t r0 = (uint64_t)blockIdx.x * kWaveRecs;
     const uint32_t live = (n - r0 < (uint64_t)kWaveRecs) ? (uint32_t)(n - r0) : (uint32_t)kWaveRecs;
-    {
-        const u4v *src = reinterpret_cast<const u4v *>(in + r0 * kRecIn);
-        const uint32_t chunks = live * (kRecIn / 4);
-        u4v v[kRecIn / 4];
-#pragma unroll
-        for (int j = 0; j < kRecIn / 4; ++j) {
-            const uint32_t g = (uint32_t)j * 64u + lane;
-            v[j] = (g < chunks) ? __builtin_nontemporal_load(src + g) : u4v{0u, 0u, 0u, 0u};
-        }
-#pragma unroll
-        for (int j = 0; j < kRecIn / 4; ++j) reinterpret_cast<u4v *>(s_rec)[j * 64 + lane] = v[j];
-    }
-    __syncthreads();
+    stream_stage(in, r0, live, lane, s_rec, s_op);
     const bool have = (uint32_t)lane < live;
     uint32_t w[kRecOut], op, reset;
     float sum0, sum1;
-    const bool known = stream_eval_record(s_rec, lane, have, extended, w, op, reset, sum0, sum1);
+    const bool known = stream_eval_compact(reinterpret_cast<const u4v *>(s_rec) + lane * kLiveStride, s_op[lane], have, extended, w, op, reset, sum0, sum1);
     if (__ballot(!known) && lane == 0) atomicOr(ch.sticky + 1, 1ull);
 
     if (extended) {
