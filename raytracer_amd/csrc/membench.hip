@@ -146,6 +146,39 @@ template <typename T, int RS, int WS, bool WIDE> static void run_mix(const char 
 // and writes RECS 84-byte records; THREADS per workgroup, every wave with a span of its own.  No arithmetic beyond what keeps
 // the loads alive.
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+// The same with the loads of a wave issued in GROUPS portions, each waited for before the next goes out: fewer bytes in
+// flight per wave at the price of GROUPS memory round trips in the life of a wave.
+template <int GROUPS>
+__global__ __launch_bounds__(64) void k_rec_grouped(const u4v *in, u4v *out, size_t n_rec) {
+    const int lane = threadIdx.x;
+    const size_t r0 = (size_t)blockIdx.x * 64;
+    if (r0 >= n_rec) return;
+    const u4v *src = in + r0 * 21;
+    u4v acc = u4v{0u, 0u, 0u, 0u};
+    constexpr int PER = 21 / GROUPS;
+#pragma unroll
+    for (int g0 = 0; g0 < GROUPS; ++g0) {
+        u4v v[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) v[j] = __builtin_nontemporal_load(src + (g0 * PER + j) * 64 + lane);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) acc ^= v[j];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    u4v *dst = out + (r0 * 21) / 4;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int g = j * 64 + lane;
+        if (g < 336) __builtin_nontemporal_store(acc, dst + g);
+    }
+}
+
+template <int GROUPS> static void run_rec_grouped(const char *name, const void *in, void *out, size_t n_rec, unsigned lds) {
+    const unsigned blocks = (unsigned)((n_rec + 63) / 64);
+    double ms = time_ms([&] { hipLaunchKernelGGL((k_rec_grouped<GROUPS>), dim3(blocks), dim3(64), lds, 0, (const u4v *)in, (u4v *)out, n_rec); });
+    printf("%-44s lds %6u  %8.1f GB/s  (%.3f ms, 420 B per record)\n", name, lds, n_rec * 420.0 / ms / 1e6, ms);
+}
+
 template <int THREADS, int RECS, bool NT_LD, bool NT_ST>
 __global__ __launch_bounds__(THREADS) void k_rec(const u4v *in, u4v *out, size_t n_rec) {
     const int lane = threadIdx.x & 63;
@@ -196,7 +229,77 @@ static void rec_probes(void *a, void *b, size_t bytes) {
         run_rec<256, 32, true, true>("rec 256 thr, 32 rec/wave, nt ld, nt st", a, b, n_rec, lds);
         run_rec<64, 16, true, true>("rec 64 thr, 16 rec/wave, nt ld, nt st", a, b, n_rec, lds);
         run_rec<256, 16, true, true>("rec 256 thr, 16 rec/wave, nt ld, nt st", a, b, n_rec, lds);
+        run_rec_grouped<1>("rec 64 thr, 64 rec/wave, 1 group", a, b, n_rec, lds);
+        run_rec_grouped<3>("rec 64 thr, 64 rec/wave, 3 groups", a, b, n_rec, lds);
+        run_rec_grouped<7>("rec 64 thr, 64 rec/wave, 7 groups", a, b, n_rec, lds);
     }
+}
+
+// The record-stream pattern with arithmetic behind the loads (WORK dependent multiply-adds per loaded chunk) in workgroups of
+// WAVES waves; with TOKEN at most one wave of a workgroup has loads in flight at a time (a lock in LDS): do fewer, shorter load
+// phases per CU (a smaller window of open DRAM pages) pay when many waves are needed to cover the arithmetic?
+template <int WAVES, bool TOKEN, int WORK>
+__global__ __launch_bounds__(WAVES * 64) void k_rec_token(const u4v *in, u4v *out, size_t n_rec) {
+    __shared__ int s_lock;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) s_lock = 0;
+    __syncthreads();
+    const size_t wave = (size_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const size_t r0 = wave * 64;
+    if (r0 >= n_rec) return;
+    const u4v *src = in + r0 * 21;
+    u4v v[21];
+    if (TOKEN) {
+        if (lane == 0) while (atomicCAS(&s_lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int j = 0; j < 21; ++j) v[j] = __builtin_nontemporal_load(src + j * 64 + lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (TOKEN) {
+        if (lane == 0) atomicExch(&s_lock, 0);
+    }
+    u4v acc = u4v{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 21; ++j) {
+        u4v t = v[j];
+        for (int k = 0; k < WORK; ++k) t = t * 1664525u + 1013904223u;
+        acc ^= t;
+    }
+    u4v *dst = out + (r0 * 21) / 4;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int g = j * 64 + lane;
+        if (g < 336) __builtin_nontemporal_store(acc, dst + g);
+    }
+}
+
+template <int WAVES, bool TOKEN, int WORK> static void run_rec_token(const char *name, const void *in, void *out, size_t n_rec, unsigned lds) {
+    const unsigned blocks = (unsigned)((n_rec / 64 + WAVES - 1) / WAVES);
+    double ms = time_ms([&] { hipLaunchKernelGGL((k_rec_token<WAVES, TOKEN, WORK>), dim3(blocks), dim3(WAVES * 64), lds, 0, (const u4v *)in, (u4v *)out, n_rec); });
+    printf("%-44s lds %6u  %8.1f GB/s  (%.3f ms, 420 B per record)\n", name, lds, n_rec * 420.0 / ms / 1e6, ms);
+}
+
+static void token_probes(void *a, void *b, size_t bytes) {
+    size_t n_rec = bytes / 336;
+    if (n_rec > ((size_t)1 << 24)) n_rec = (size_t)1 << 24;
+    // one workgroup per CU (12 and 8 waves), two (6 waves each), three (4 each), residency forced by unused LDS
+    run_rec_token<6, false, 0>("6 waves x2, free, no work", a, b, n_rec, 66560);
+    run_rec_token<6, true, 0>("6 waves x2, token, no work", a, b, n_rec, 66560);
+    run_rec_token<6, false, 8>("6 waves x2, free, work 8", a, b, n_rec, 66560);
+    run_rec_token<6, true, 8>("6 waves x2, token, work 8", a, b, n_rec, 66560);
+    run_rec_token<6, false, 16>("6 waves x2, free, work 16", a, b, n_rec, 66560);
+    run_rec_token<6, true, 16>("6 waves x2, token, work 16", a, b, n_rec, 66560);
+    run_rec_token<4, false, 8>("4 waves x3, free, work 8", a, b, n_rec, 43520);
+    run_rec_token<4, true, 8>("4 waves x3, token, work 8", a, b, n_rec, 43520);
+    run_rec_token<4, false, 16>("4 waves x3, free, work 16", a, b, n_rec, 43520);
+    run_rec_token<4, true, 16>("4 waves x3, token, work 16", a, b, n_rec, 43520);
+    run_rec_token<12, false, 8>("12 waves x1, free, work 8", a, b, n_rec, 133120);
+    run_rec_token<12, true, 8>("12 waves x1, token, work 8", a, b, n_rec, 133120);
+    run_rec_token<12, false, 16>("12 waves x1, free, work 16", a, b, n_rec, 133120);
+    run_rec_token<12, true, 16>("12 waves x1, token, work 16", a, b, n_rec, 133120);
+    run_rec_token<1, false, 8>("1 wave x12, free, work 8", a, b, n_rec, 11520);
+    run_rec_token<1, false, 16>("1 wave x12, free, work 16", a, b, n_rec, 11520);
 }
 
 int main(int argc, char **argv) {
@@ -209,6 +312,22 @@ int main(int argc, char **argv) {
     CK(hipMemset(a, 0x11, bytes));
     CK(hipMemset(b, 0x22, bytes));
     CK(hipDeviceSynchronize());
+    if (argc > 3 && !strcmp(argv[3], "token")) {  // throttled load phases
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_token<12, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 140000));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_token<12, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 140000));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_token<12, false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 140000));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_token<12, true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 140000));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_token<6, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 140000));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_token<6, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 140000));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_token<6, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 140000));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_token<6, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 140000));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_token<6, false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 140000));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_token<6, true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 140000));
+        token_probes(a, b, bytes);
+        CK(hipFree(a));
+        CK(hipFree(b));
+        return 0;
+    }
     if (argc > 3 && !strcmp(argv[3], "rec")) {  // only the record-stream pattern
         rec_probes(a, b, bytes);
         CK(hipFree(a));
