@@ -433,9 +433,10 @@ def _single_pass_case(oracle, torch, stream, what, chunk_log2=None, monkeypatch=
     c.close()
 
 
-def test_single_pass_record_stream_long_stretches_without_an_opcode(oracle, torch_cuda):
-    """The running sum of a vector pair has to cross thousands of records that hold no beat of its opcode: the look-back skips
-    the waves in between 64 at a time."""
+@pytest.mark.parametrize("mode", [2, 3])
+def test_record_stream_long_stretches_without_an_opcode(oracle, torch_cuda, mode):
+    """The running sum of a vector pair has to cross thousands of records that hold no beat of its opcode: the look-back
+    (mode 3) and the fold (mode 2) skip the waves in between 64 at a time."""
     torch = torch_cuda
     rng = np.random.default_rng(5)
     a, b, ctl, _ = gen.vec_beats(6, 16, seed=51, lengths=[40, 100, 16, 128, 7, 90])
@@ -458,11 +459,28 @@ def test_single_pass_record_stream_long_stretches_without_an_opcode(oracle, torc
     stream = np.ascontiguousarray(np.concatenate(parts)).astype(u32)
     stream[stream[:, 0] < 2, 83] = 1
     assert stream.shape[0] > 100000
-    _single_pass_case(oracle, torch, stream, "sparse distance beats")
+    _single_pass_case(oracle, torch, stream, "sparse distance beats", mode=mode)
 
 
-@pytest.mark.parametrize("kind", ["box_only", "euclid_only", "angular_only", "no_reset", "reset_everywhere", "tail_of_7"])
-def test_single_pass_record_stream_corner_streams(oracle, torch_cuda, kind):
+@pytest.mark.parametrize("mode", [2, 3])
+def test_record_stream_pairs_open_across_half_a_million_records(oracle, torch_cuda, mode):
+    """Distance beats at both ends of a stream and nowhere in between: the fold's bit words are crossed 64 words (2^18 records)
+    at a time, in both directions; one opcode's pair stays open across the gap, the other's is closed in front of it."""
+    torch = torch_cuda
+    a, b, ctl, _ = gen.vec_beats(3, 16, seed=61, lengths=[70, 9, 75])
+    q, cnd, ctl8, _ = gen.vec_beats(3, 8, seed=62, lengths=[66, 5, 80])
+    we, wa = gen.aos_from_vec(a, b, ctl, 2), gen.aos_from_vec(q, cnd, ctl8, 3)
+    box = gen.aos_from_box(gen.box_ops(1 << 15, seed=63, edge_frac=0.1))
+    gap = np.concatenate([box] * 17)[:(1 << 19) + 777]
+    # front: the first Euclidean pair and 4 beats of the second, the first angular pair complete; back: everything else
+    stream = np.ascontiguousarray(np.concatenate([we[:74], wa[:66], gap, wa[66:], we[74:], gap[:5000], wa[:3]])).astype(u32)
+    stream[stream[:, 0] < 2, 83] = 1
+    _single_pass_case(oracle, torch, stream, "beats at both ends only", mode=mode)
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("kind", ["box_only", "euclid_only", "angular_only", "no_reset", "reset_everywhere", "tail_of_7", "few_resets"])
+def test_record_stream_corner_streams(oracle, torch_cuda, kind, mode):
     torch = torch_cuda
     base = _mixed_stream(90, 3000, 3000, 500, 500)
     if kind == "box_only":
@@ -477,9 +495,13 @@ def test_single_pass_record_stream_corner_streams(oracle, torch_cuda, kind):
     elif kind == "reset_everywhere":
         stream = base.copy()
         stream[:, 83] = 1
+    elif kind == "few_resets":  # pairs that run through dozens of waves, some waves with more than four head beats
+        stream = np.concatenate([base, base, base])
+        keep = np.random.default_rng(93).random(stream.shape[0]) < 0.02
+        stream[(stream[:, 0] >= 2) & ~keep, 83] = 0
     else:
         stream = base[:7]
-    _single_pass_case(oracle, torch, np.ascontiguousarray(stream), kind)
+    _single_pass_case(oracle, torch, np.ascontiguousarray(stream), kind, mode=mode)
 
 
 @pytest.mark.parametrize("mode", [2, 3])
