@@ -82,7 +82,8 @@ def test_two_rank_rehearsal_line():
     d = check_line(r.stdout, 2, 3, 1)
     assert d["cpu_baseline"] is None
     assert set(d["per_opcode"]) == {"box", "tri", "euclid", "angular", "mixed", "box_plain", "tri_plain", "box_edge", "tri_edge",
-                                    "pack_box", "pack_tri", "mixed_2p20", "mixed_2p20_plain", "knn"}
+                                    "pack_box", "pack_tri", "mixed_2p20", "mixed_2p20_plain", "record_stream", "knn"}
+    assert d["per_opcode"]["record_stream"]["unit"] == "records/s" and d["per_opcode"]["record_stream"]["roofline"]["frac"] > 0
     assert d["per_opcode"]["knn"]["exhaustive"]["exchange"] == "gloo (host staging)"     # the rehearsal never touches RCCL
     assert d["per_opcode"]["box"]["layout"] == "tiled" and d["per_opcode"]["box_plain"]["layout"] == "plain"
     assert d["per_opcode"]["euclid"]["layout"] == "plain"
