@@ -319,9 +319,14 @@ typedef struct rt_dp_output_bundle {
 int rt_dp_eval_bundles(rt_dp_ctx *ctx, const rt_dp_input_bundle *in, rt_dp_output_bundle *out, uint64_t n);
 
 /* The same contract for a record stream that already lives in HBM (device pointers,
- * n < 2^29): the opcode partition (stable, so every accumulator sees its beats in
- * stream order), the evaluation and the re-assembly of the output records all run on
- * the GPU; only the four per-opcode counts travel to the host.  Synchronous.           */
+ * n < 2^29); everything runs on the GPU and the records are read once, in place.  With
+ * 16-byte aligned arrays (option "stream_mode" 0 / 2) one kernel evaluates every record
+ * where it lies and a second, small one adds the distance beats that continue a vector
+ * pair from an earlier part of the stream onto that pair's running sum, in stream order;
+ * the context keeps a workspace of about 12.6 bytes per record of a piece (pieces of at
+ * most 2^26 records).  Otherwise ("stream_mode" 1) the records are partitioned by opcode
+ * first (stable, so every accumulator sees its beats in stream order), evaluated by the
+ * batch kernels and re-assembled.  Same bits either way.  Synchronous.                   */
 int rt_dp_eval_bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt_dp_output_bundle *d_out, uint64_t n);
 
 /* ---- one stream over several contexts / GPUs -----------------------------------------------
