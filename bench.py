@@ -445,12 +445,22 @@ def stream_measure(a, world, rank, local, dev, log2_n, mode, steps, warmup):
     del rec, out
     torch.cuda.empty_cache()
     per = wall / steps
+    kernels = "rtdp::k_stream_bits + rtdp::k_stream_eval + rtdp::k_stream_fold" if mode in (0, 2) else "mode %d" % mode
+    try:
+        passes = json.load(open(TRAFFIC_FILE))
+    except Exception:  # noqa: BLE001
+        passes = {}
+    measured = passes.get("record_stream") if mode in (0, 2) else None
+    fresh = bool(measured) and measured.get("kernel") == kernels
     return {"metric": "datapath records/s (AoS record stream, mixed opcodes)", "value": round(n * world / per, 1), "unit": "records/s",
             "ms_per_step": round(per * 1e3, 4), "steps": steps, "warmup": warmup, "scaling": "weak",
             "workload": "stream: 2^%d EnhancedInputBundle records per GPU resident in HBM, opcode ~ U{0..3}" % log2_n,
             "roofline": {"bound": "hbm", "achieved": round(n * 420 / per / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(n * 420 / per / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernels": {"stream": "rtdp::k_stream_eval + rtdp::k_stream_bits + rtdp::k_stream_fold" if mode in (0, 2) else "mode %d" % mode},
+                         "frac": round(n * 420 / per / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": int(measured["hbm_bytes_per_unit"] * n) if fresh else None,
+                         "traffic_source": ("profiles/traffic.json (%s)" % passes.get("_source", "") + ", per-record counter figures x the records of this call; not re-measured in this run") if fresh
+                                           else "stale or absent: no counter pass of " + kernels,
+                         "kernels": {"stream": kernels},
                          "note": "420 B per record = 336 B record in + 84 B record out; wall time per synchronous call; mode %d (1: partition first, moves every live operand twice more; 0/2: evaluate in place, then fold the beats; 3: one pass)" % mode}}
 
 

@@ -36,6 +36,10 @@ done
 for c in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "valu:SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES" "grbm:GRBM_GUI_ACTIVE"; do
     run "${c%%:*}_angular_short" 120 rocprofv3 --pmc ${c#*:} --output-format csv -d "$OUT/pmc_${c%%:*}_angular_short" -- $BENCH --only angular --log2-ops 22 --steps 3 --warmup 1
 done
+# the record-stream front end (evaluate in place, then fold): bytes per record of its three kernels
+for c in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "valu:SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES"; do
+    run "${c%%:*}_stream" 120 rocprofv3 --pmc ${c#*:} --output-format csv -d "$OUT/pmc_${c%%:*}_stream" -- python3 $ROOT/bench.py --only stream --stream-mode 2 --steps 3 --warmup 1
+done
 # the drivers above the op kernels: record stream (both modes), k-NN (exhaustive and tree), traversal (both walks)
 for spec in "stream1:--only stream --stream-mode 1" "stream2:--only stream --stream-mode 2" "knn_exhaustive:--only knn --knn-tree 0" \
             "knn_tree_walk:--only knn --knn-tree 1" "knn_tree_leafmajor:--only knn --knn-tree 2" "trace_dfs:--only trace" "trace_dfs_sorted:--only trace --trace-sorted 1" "trace_wavefront:--only trace --trace-wavefront 1" "trace_device_built:--only trace --trace-build device" \

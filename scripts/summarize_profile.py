@@ -29,7 +29,7 @@ csv.field_size_limit(1 << 30)
 
 
 def short(name):
-    m = re.search(r"(rtdp::k_\w+<[^>]*>|k_read<[^>]*>|k_copy<[^>]*>)", name)
+    m = re.search(r"(rtdp::k_\w+<[^>]*>|k_read<[^>]*>|k_copy<[^>]*>|rtdp::k_stream_\w+)", name)
     return m.group(1) if m else None
 
 
@@ -147,6 +147,28 @@ for op, (prefix, total, rd, wr) in UNITS.items():
     traffic[op] = {"hbm_bytes_per_unit": round(fb + wb, 2), "fetched": round(fb, 2), "written": round(wb, 2),
                    "algorithmic": total, "units": n, "kernel": key[0]}
     lines.append("| %s | `%s` | %d | %.2f (%d) | %.2f (%d) | %.2f (%d) |" % (op, key[0], n, fb, rd, wb, wr, fb + wb, total))
+# ---- the record-stream front end: its kernels' bytes per record (2^24 records per call unless the pass says otherwise)
+sf = pmc("pmc_fetch_stream/*/*counter_collection.csv", "FETCH_SIZE")
+sw = pmc("pmc_write_stream/*/*counter_collection.csv", "WRITE_SIZE")
+si = pmc("pmc_valu_stream/*/*counter_collection.csv", "SQ_INSTS_VALU")
+sv = pmc("pmc_valu_stream/*/*counter_collection.csv", "SQ_WAVES")
+if sf and sw:
+    n_rec = 1 << 24
+    lines += ["\n## Record stream, evaluate in place then fold (`bench.py --only stream --stream-mode 2`, 2^24 records per call)\n",
+              "| kernel | fetched B/record | written B/record | VALU instructions per wave |\n|---|---|---|---|"]
+    tf = tw = 0.0
+    names = []
+    for key in sorted(sf):
+        if not key[0].startswith("rtdp::k_stream_") or key not in sw:
+            continue
+        fb, wb = med(sf[key]) * 1024 * ffac / n_rec, med(sw[key]) * 1024 * wfac / n_rec
+        tf, tw = tf + fb, tw + wb
+        names.append(key[0])
+        vi = ("%.0f" % (med(si[key]) / med(sv[key]))) if key in si and key in sv and med(sv[key]) else "-"
+        lines.append("| `%s` | %.2f | %.2f | %s |" % (key[0], fb, wb, vi))
+    lines.append("| all | %.2f (336) | %.2f (84) | |" % (tf, tw))
+    traffic["record_stream"] = {"hbm_bytes_per_unit": round(tf + tw, 2), "fetched": round(tf, 2), "written": round(tw, 2), "algorithmic": 420,
+                                "units": n_rec, "kernel": " + ".join(names)}
 # ---- VALU issue and clock
 def pmc_timed(pattern, counter, prefix):
     vals, durs = [], []
