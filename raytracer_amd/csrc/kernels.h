@@ -99,6 +99,8 @@ hipError_t launch_ray_prepare(const RayPrepArgs &args, uint64_t n, hipStream_t s
 // out_d / out_i: [splits][n_qry][16], ascending by (distance, index); unused slots hold (+Inf, 0xFFFFFFFF).
 hipError_t launch_knn_euclid16(const float *pts, uint32_t n_pts, const float *qry, uint32_t n_qry, uint32_t idx_base,
                                uint32_t splits, bool angular, float *out_d, uint32_t *out_i, hipStream_t stream);
+// dynamic LDS (never touched) that keeps `wgs_per_cu` workgroups of `threads` threads of `kernel` resident per CU, verified with the occupancy query
+unsigned residency_pad(const void *kernel, int threads, int wgs_per_cu);
 // fused record-stream path (stream_fused.hip)
 struct StreamSideView {
     const float *hs[3];

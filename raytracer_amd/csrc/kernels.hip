@@ -1246,10 +1246,10 @@ struct Residency { unsigned lds; int achieved; };
 
 constexpr unsigned kMaxLdsPerWorkgroup = 65536u;  // static + dynamic; more would need a function attribute
 
-static Residency resolve_residency(const void *kernel, int w, unsigned static_lds) {
+static Residency resolve_residency(const void *kernel, int w, unsigned static_lds, int threads = 256) {
     auto occupancy = [&](unsigned lds) -> int {
         int blocks = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, 256, lds) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, threads, lds) != hipSuccess) { (void)hipGetLastError(); return -1; }
         return blocks;
     };
     const unsigned room = kMaxLdsPerWorkgroup > static_lds ? kMaxLdsPerWorkgroup - static_lds : 0u;
@@ -1291,6 +1291,26 @@ static Residency residency(const void *kernel, int wgs, int dflt) {
 }
 
 static unsigned residency_lds(const void *kernel, int wgs, int dflt) { return residency(kernel, wgs, dflt).lds; }
+
+// The same for a kernel of another file with workgroups of `threads` threads: the dynamic LDS to launch it with so that `w`
+// workgroups stay resident per CU (resolved once per device and kernel).
+unsigned residency_pad(const void *kernel, int threads, int w) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    static std::mutex lock;
+    static std::map<std::tuple<int, const void *, int>, unsigned> cache;
+    std::lock_guard<std::mutex> hold(lock);
+    const auto key = std::make_tuple(dev, kernel, w);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    hipFuncAttributes attr;
+    unsigned static_lds = 0u;
+    if (hipFuncGetAttributes(&attr, kernel) == hipSuccess) static_lds = (unsigned)attr.sharedSizeBytes;
+    else (void)hipGetLastError();
+    const unsigned lds = resolve_residency(kernel, w, static_lds, threads).lds;
+    cache.emplace(key, lds);
+    return lds;
+}
 
 // What the box / triangle launches of a large batch get with these settings: resident 256-thread workgroups per CU
 // (0 = no cap) as the occupancy query reports it for the dynamic-LDS size in use.

@@ -114,7 +114,9 @@ __device__ __forceinline__ uint32_t live_chunks(uint32_t op) {
     return op == 1u ? kLiveBox : op == 0u ? kLiveTri : op == 2u ? kLiveEuc : op == 3u ? kLiveAng : 0u;
 }
 
-// stream_eval_record over the compact slots of the lane's record (rc = 11 slots).  Same arithmetic, same outputs.
+// One lane evaluates the record it owns out of its compact row (rc = 11 slots): Quadbox and triangle ops completely, for a
+// distance beat the tree sum(s) of the beat, which do not depend on the accumulator.  w: the 21 output words (accumulator
+// fields still 0).  Returns false when the opcode is not one of the four.
 __device__ __forceinline__ bool stream_eval_compact(const u4v *rc, uint32_t op_in, bool have, int extended, uint32_t (&w)[kRecOut], uint32_t &op,
                                                     uint32_t &reset, float &sum0, float &sum1) {
     bool known = true;
@@ -209,46 +211,54 @@ __device__ __forceinline__ bool stream_eval_compact(const u4v *rc, uint32_t op_i
     return known;
 }
 
-// The wave's records from HBM into the compact rows of s_rec (11 slots of 16 bytes per record) and their opcodes into s_op.
+constexpr int kStreamEvalWavesPerCu = 9;  // resident waves of k_stream_eval per CU (environment RT_DP_STREAM_WAVES: another number, 0 = whatever fits)
+constexpr int kStageWords = (kWaveRecs * kLiveStride + kWaveRecs) * 4;  // the compact rows and, behind them, one slot per lane for chunks nobody reads
+
+// The wave's records from HBM into the compact rows of s_rec (11 slots of 16 bytes per record); s_op[r] receives record r's
+// opcode << 24 | the mask of its live chunks (0 for a record behind the stream's end).  Straight-line code: a chunk that no
+// opcode body reads goes to the lane's own spare slot instead of being skipped, so the 21 LDS writes need no branches.
 __device__ __forceinline__ void stream_stage(const uint32_t *__restrict__ in, uint64_t r0, uint32_t live, int lane, uint32_t *s_rec, uint32_t *s_op) {
     // Coalesced loads of the wave's whole records (chunk g = j * 64 + lane of its 21 KiB); fetching only the chunks a record's
     // opcode reads measured 9-11 % slower on MI355X -- the lines come in full anyway.  Chunk g belongs to record g / 21; 64 = 3 * 21 + 1,
     // so from one load to the next a lane moves three records on and one chunk up (four records on where the chunk wraps).
-    {
-        const u4v *src = reinterpret_cast<const u4v *>(in + r0 * kRecIn);
+    const u4v *src = reinterpret_cast<const u4v *>(in + r0 * kRecIn);
+    u4v v[kRecIn / 4];
+    if (live == (uint32_t)kWaveRecs) {
+#pragma unroll
+        for (int j = 0; j < kRecIn / 4; ++j) v[j] = __builtin_nontemporal_load(src + j * 64 + lane);
+    } else {
         const uint32_t chunks = live * (kRecIn / 4);
-        u4v v[kRecIn / 4];
 #pragma unroll
         for (int j = 0; j < kRecIn / 4; ++j) {
             const uint32_t g = (uint32_t)j * 64u + lane;
             v[j] = (g < chunks) ? __builtin_nontemporal_load(src + g) : u4v{0u, 0u, 0u, 0u};
         }
-        const uint32_t rec0 = (uint32_t)lane / 21u, chunk0 = (uint32_t)lane % 21u;
-        // the lane that holds a record's first chunk posts its opcode
+    }
+    const uint32_t rec0 = (uint32_t)lane / 21u, chunk0 = (uint32_t)lane % 21u;
+    {   // Exactly one of a lane's 21 chunks is the first chunk of a record (64 lanes, 64 records): that lane posts the record's opcode.
+        const uint32_t jstar = (21u - chunk0) % 21u;
+        uint32_t op = 0u;
 #pragma unroll
-        for (int j = 0; j < kRecIn / 4; ++j) {
-            const uint32_t wrap = (chunk0 + (uint32_t)j >= 21u) ? 1u : 0u;
-            const uint32_t c = chunk0 + (uint32_t)j - 21u * wrap, r = rec0 + 3u * (uint32_t)j + wrap;
-            if (c == 0u && r < (uint32_t)kWaveRecs) s_op[r] = v[j].x;
-        }
-        __syncthreads();
-        // every chunk goes to its slot in its record's compact row, or nowhere
+        for (int j = 0; j < kRecIn / 4; ++j) op = (jstar == (uint32_t)j) ? v[j].x : op;
+        const uint32_t rstar = rec0 + 3u * jstar + (chunk0 != 0u ? 1u : 0u);
+        if (rstar < (uint32_t)kWaveRecs) s_op[rstar] = (rstar < live) ? (((op > 3u ? 0xFFu : op) << 24) | live_chunks(op)) : 0u;  // 0xFF: not an opcode
+    }
+    __syncthreads();
 #pragma unroll
-        for (int j = 0; j < kRecIn / 4; ++j) {
-            const uint32_t wrap = (chunk0 + (uint32_t)j >= 21u) ? 1u : 0u;
-            const uint32_t c = chunk0 + (uint32_t)j - 21u * wrap, r = rec0 + 3u * (uint32_t)j + wrap;
-            if (r < live) {
-                const uint32_t m = live_chunks(s_op[r]);
-                if ((m >> c) & 1u) reinterpret_cast<u4v *>(s_rec)[r * kLiveStride + __popc(m & ((1u << c) - 1u))] = v[j];
-            }
-        }
+    for (int j = 0; j < kRecIn / 4; ++j) {
+        const uint32_t wrap = (chunk0 + (uint32_t)j >= 21u) ? 1u : 0u;
+        const uint32_t c = chunk0 + (uint32_t)j - 21u * wrap, r = rec0 + 3u * (uint32_t)j + wrap;
+        const uint32_t m = (r < (uint32_t)kWaveRecs) ? s_op[r] : 0u;
+        const bool keep = (m >> c) & 1u;
+        const uint32_t slot = keep ? (r * kLiveStride + __popc(m & ((1u << c) - 1u))) : ((uint32_t)(kWaveRecs * kLiveStride) + lane);
+        reinterpret_cast<u4v *>(s_rec)[slot] = v[j];
     }
     __syncthreads();
 }
 
 __global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__ in, uint64_t n, int extended, uint32_t *__restrict__ out,
                                                     StreamSide side) {
-    __shared__ __align__(16) uint32_t s_rec[kWaveRecs * kLiveStride * 4];  // 11 KiB of live chunks; re-used for the output records (5.25 KiB)
+    __shared__ __align__(16) uint32_t s_rec[kStageWords];  // 12 KiB: live chunks and spare slots; re-used for the output records (5.25 KiB)
     __shared__ uint32_t s_op[kWaveRecs];
     const int lane = threadIdx.x;
     const uint64_t r0 = (uint64_t)blockIdx.x * kWaveRecs;
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__
     const bool have = (uint32_t)lane < live;
     uint32_t w[kRecOut], op, reset;
     float sum0, sum1;
-    if (!stream_eval_compact(reinterpret_cast<const u4v *>(s_rec) + lane * kLiveStride, s_op[lane], have, extended, w, op, reset, sum0, sum1))
+    if (!stream_eval_compact(reinterpret_cast<const u4v *>(s_rec) + lane * kLiveStride, s_op[lane] >> 24, have, extended, w, op, reset, sum0, sum1))
         atomicOr(&side.flags[8], 1u);
 
     // Beats behind the first reset of their opcode in this wave start from +0 whatever came before: their accumulator
@@ -674,7 +684,7 @@ __device__ __forceinline__ void stream_wave_fold(unsigned long long e, unsigned 
 
 __global__ __launch_bounds__(64) void k_stream_chain(const uint32_t *__restrict__ in, uint64_t n, int extended, uint32_t *__restrict__ out,
                                                      StreamChain ch, const float *__restrict__ state_in, int mute) {
-    __shared__ __align__(16) uint32_t s_rec[kWaveRecs * kLiveStride * 4];  // 11 KiB of live chunks; re-used for the output records
+    __shared__ __align__(16) uint32_t s_rec[kStageWords];  // 12 KiB: live chunks and spare slots; re-used for the output records
     __shared__ uint32_t s_op[kWaveRecs];
     const int lane = threadIdx.x;
     const uint64_t r0 = (uint64_t)blockIdx.x * kWaveRecs;
@@ -683,7 +693,7 @@ __global__ __launch_bounds__(64) void k_stream_chain(const uint32_t *__restrict_
     const bool have = (uint32_t)lane < live;
     uint32_t w[kRecOut], op, reset;
     float sum0, sum1;
-    const bool known = stream_eval_compact(reinterpret_cast<const u4v *>(s_rec) + lane * kLiveStride, s_op[lane], have, extended, w, op, reset, sum0, sum1);
+    const bool known = stream_eval_compact(reinterpret_cast<const u4v *>(s_rec) + lane * kLiveStride, s_op[lane] >> 24, have, extended, w, op, reset, sum0, sum1);
     if (__ballot(!known) && lane == 0) atomicOr(ch.sticky + 1, 1ull);
 
     if (extended) {
@@ -811,7 +821,13 @@ hipError_t stream_fused_eval(const uint32_t *in, uint64_t n, uint64_t capacity, 
     if (n > capacity || nblk > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(side.flags, 0, first_piece ? 256 : 32, s);  // the per-piece flags (all flags on the first piece)
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_stream_eval, dim3((unsigned)nblk), dim3(64), 0, s, in, n, extended, out, side);
+    // Eight or nine waves per CU: with fewer the kernel's instructions are not covered, with more the memory system sees more
+    // open 21 KiB spans than it serves well (MI355X, ms per call at 2^22 / 2^24 / 2^26 records: 7 waves 0.377 / 1.27 / 4.85,
+    // 8: 0.355 / 1.22 / 4.85, 9: 0.340 / 1.22 / 4.90, 12: 0.350 / 1.30 / 5.36).
+    static const int waves_env = getenv("RT_DP_STREAM_WAVES") ? atoi(getenv("RT_DP_STREAM_WAVES")) : -1;
+    const int waves = waves_env >= 0 ? waves_env : kStreamEvalWavesPerCu;
+    const unsigned pad = waves > 0 ? residency_pad(reinterpret_cast<const void *>(&k_stream_eval), 64, waves) : 0u;
+    hipLaunchKernelGGL(k_stream_eval, dim3((unsigned)nblk), dim3(64), pad, s, in, n, extended, out, side);
     if (extended) hipLaunchKernelGGL(k_stream_bits, dim3((unsigned)(((nblk + 63) / 64 + 255) / 256)), dim3(256), 0, s, side, nblk);
     view->hs[0] = side.hs[0]; view->hs[1] = side.hs[1]; view->hs[2] = side.hs[2]; view->heads = side.heads; view->tails = side.tails;
     view->occ[0] = side.occ[0]; view->occ[1] = side.occ[1]; view->rst[0] = side.rst[0]; view->rst[1] = side.rst[1]; view->flags = side.flags;
