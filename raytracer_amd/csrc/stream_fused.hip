@@ -211,7 +211,7 @@ __device__ __forceinline__ bool stream_eval_compact(const u4v *rc, uint32_t op_i
     return known;
 }
 
-constexpr int kStreamEvalWavesPerCu = 9;  // resident waves of k_stream_eval per CU (environment RT_DP_STREAM_WAVES: another number, 0 = whatever fits)
+constexpr int kStreamEvalWavesPerCu = 8;  // resident waves of k_stream_eval per CU (environment RT_DP_STREAM_WAVES: another number, 0 = whatever fits)
 constexpr int kStageWords = (kWaveRecs * kLiveStride + kWaveRecs) * 4;  // the compact rows and, behind them, one slot per lane for chunks nobody reads
 
 // The wave's records from HBM into the compact rows of s_rec (11 slots of 16 bytes per record); s_op[r] receives record r's
@@ -241,14 +241,15 @@ __device__ __forceinline__ void stream_stage(const uint32_t *__restrict__ in, ui
 #pragma unroll
         for (int j = 0; j < kRecIn / 4; ++j) op = (jstar == (uint32_t)j) ? v[j].x : op;
         const uint32_t rstar = rec0 + 3u * jstar + (chunk0 != 0u ? 1u : 0u);
-        if (rstar < (uint32_t)kWaveRecs) s_op[rstar] = (rstar < live) ? (((op > 3u ? 0xFFu : op) << 24) | live_chunks(op)) : 0u;  // 0xFF: not an opcode
+        s_op[rstar] = (rstar < live) ? (((op > 3u ? 0xFFu : op) << 24) | live_chunks(op)) : 0u;  // 0xFF: not an opcode (the 64 lanes cover the 64 records)
+        if (lane == 0) s_op[kWaveRecs] = 0u;
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < kRecIn / 4; ++j) {
         const uint32_t wrap = (chunk0 + (uint32_t)j >= 21u) ? 1u : 0u;
         const uint32_t c = chunk0 + (uint32_t)j - 21u * wrap, r = rec0 + 3u * (uint32_t)j + wrap;
-        const uint32_t m = (r < (uint32_t)kWaveRecs) ? s_op[r] : 0u;
+        const uint32_t m = s_op[r];  // r <= 64, and entry 64 is 0
         const bool keep = (m >> c) & 1u;
         const uint32_t slot = keep ? (r * kLiveStride + __popc(m & ((1u << c) - 1u))) : ((uint32_t)(kWaveRecs * kLiveStride) + lane);
         reinterpret_cast<u4v *>(s_rec)[slot] = v[j];
@@ -259,7 +260,7 @@ __device__ __forceinline__ void stream_stage(const uint32_t *__restrict__ in, ui
 __global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__ in, uint64_t n, int extended, uint32_t *__restrict__ out,
                                                     StreamSide side) {
     __shared__ __align__(16) uint32_t s_rec[kStageWords];  // 12 KiB: live chunks and spare slots; re-used for the output records (5.25 KiB)
-    __shared__ uint32_t s_op[kWaveRecs];
+    __shared__ uint32_t s_op[kWaveRecs + 1];  // one entry more: the chunk walk of stream_stage ends one record behind the wave's last
     const int lane = threadIdx.x;
     const uint64_t r0 = (uint64_t)blockIdx.x * kWaveRecs;
     const uint32_t live = (n - r0 < (uint64_t)kWaveRecs) ? (uint32_t)(n - r0) : (uint32_t)kWaveRecs;
@@ -685,7 +686,7 @@ __device__ __forceinline__ void stream_wave_fold(unsigned long long e, unsigned 
 __global__ __launch_bounds__(64) void k_stream_chain(const uint32_t *__restrict__ in, uint64_t n, int extended, uint32_t *__restrict__ out,
                                                      StreamChain ch, const float *__restrict__ state_in, int mute) {
     __shared__ __align__(16) uint32_t s_rec[kStageWords];  // 12 KiB: live chunks and spare slots; re-used for the output records
-    __shared__ uint32_t s_op[kWaveRecs];
+    __shared__ uint32_t s_op[kWaveRecs + 1];  // one entry more: the chunk walk of stream_stage ends one record behind the wave's last
     const int lane = threadIdx.x;
     const uint64_t r0 = (uint64_t)blockIdx.x * kWaveRecs;
     const uint32_t live = (n - r0 < (uint64_t)kWaveRecs) ? (uint32_t)(n - r0) : (uint32_t)kWaveRecs;
