@@ -648,7 +648,9 @@ int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value);
  * residency that box / triangle batches large enough for the cap run with, as the runtime's occupancy query
  * reports it for the launch configuration in use (0 = uncapped).  The cap is set through the amount of
  * dynamic LDS a launch asks for; the amount is verified against that query once per process, so a runtime
- * that hands out LDS differently shows up here instead of silently changing the residency.              */
+ * that hands out LDS differently shows up here instead of silently changing the residency.
+ * "stream_waves_per_cu": the same for the evaluation kernel of rt_dp_eval_bundles_device ("stream_mode" 0 / 2), in waves
+ * (its workgroups are single waves): 8 on MI355X; environment RT_DP_STREAM_WAVES asks for another number, 0 for no cap. */
 int rt_dp_get_option(rt_dp_ctx *ctx, const char *key, int *value);
 /* "vec_chain_giveups" (read only): hand-overs between workgroups of the beat kernels that were given up on after a
  * bounded wait, since the context was created.  "stream_giveups" (read only): the same count for the hand-overs

@@ -1691,6 +1691,7 @@ int rt_dp_get_option(rt_dp_ctx *ctx, const char *key, int *value) {
         *value = ctx->chain_fallbacks > 0x7FFFFFFFull ? 0x7FFFFFFF : (int)ctx->chain_fallbacks;
     } else if (!strcmp(key, "box_wgs_per_cu")) *value = resolved_residency(ctx->tuning, true);
     else if (!strcmp(key, "tri_wgs_per_cu")) *value = resolved_residency(ctx->tuning, false);
+    else if (!strcmp(key, "stream_waves_per_cu")) *value = stream_eval_waves_per_cu();
     else return fail(RT_DP_EINVAL, "unknown option '%s'", key);
     return RT_DP_OK;
 }

@@ -100,7 +100,7 @@ hipError_t launch_ray_prepare(const RayPrepArgs &args, uint64_t n, hipStream_t s
 hipError_t launch_knn_euclid16(const float *pts, uint32_t n_pts, const float *qry, uint32_t n_qry, uint32_t idx_base,
                                uint32_t splits, bool angular, float *out_d, uint32_t *out_i, hipStream_t stream);
 // dynamic LDS (never touched) that keeps `wgs_per_cu` workgroups of `threads` threads of `kernel` resident per CU, verified with the occupancy query
-unsigned residency_pad(const void *kernel, int threads, int wgs_per_cu);
+unsigned residency_pad(const void *kernel, int threads, int wgs_per_cu, int *achieved = nullptr);  // *achieved: what the query reports for that size
 // fused record-stream path (stream_fused.hip)
 struct StreamSideView {
     const float *hs[3];
@@ -109,6 +109,7 @@ struct StreamSideView {
     const uint32_t *flags;  // per launch: [1] opcode 2 present, [2] opcode 3 present, [4] / [5] 1 + the last wave holding one; [8] opcode > 3 seen (sticky, cleared by the caller)
 };
 size_t stream_fused_workspace(uint64_t capacity);
+int stream_eval_waves_per_cu();  // resident waves per CU the evaluation kernel of the two-pass form is launched with (0 = no cap)
 hipError_t stream_fused_eval(const uint32_t *in, uint64_t n, uint64_t capacity, int extended, uint32_t *out, char *workspace,
                              StreamSideView *view, hipStream_t s, bool first_piece = false);
 hipError_t stream_fused_fold(const StreamSideView &v, uint64_t n, const float *state_in, float *state_out, uint32_t *out, hipStream_t s);

@@ -1294,22 +1294,23 @@ static unsigned residency_lds(const void *kernel, int wgs, int dflt) { return re
 
 // The same for a kernel of another file with workgroups of `threads` threads: the dynamic LDS to launch it with so that `w`
 // workgroups stay resident per CU (resolved once per device and kernel).
-unsigned residency_pad(const void *kernel, int threads, int w) {
+unsigned residency_pad(const void *kernel, int threads, int w, int *achieved) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
     static std::mutex lock;
-    static std::map<std::tuple<int, const void *, int>, unsigned> cache;
+    static std::map<std::tuple<int, const void *, int>, Residency> cache;
     std::lock_guard<std::mutex> hold(lock);
     const auto key = std::make_tuple(dev, kernel, w);
     auto it = cache.find(key);
-    if (it != cache.end()) return it->second;
-    hipFuncAttributes attr;
-    unsigned static_lds = 0u;
-    if (hipFuncGetAttributes(&attr, kernel) == hipSuccess) static_lds = (unsigned)attr.sharedSizeBytes;
-    else (void)hipGetLastError();
-    const unsigned lds = resolve_residency(kernel, w, static_lds, threads).lds;
-    cache.emplace(key, lds);
-    return lds;
+    if (it == cache.end()) {
+        hipFuncAttributes attr;
+        unsigned static_lds = 0u;
+        if (hipFuncGetAttributes(&attr, kernel) == hipSuccess) static_lds = (unsigned)attr.sharedSizeBytes;
+        else (void)hipGetLastError();
+        it = cache.emplace(key, resolve_residency(kernel, w, static_lds, threads)).first;
+    }
+    if (achieved) *achieved = it->second.achieved;
+    return it->second.lds;
 }
 
 // What the box / triangle launches of a large batch get with these settings: resident 256-thread workgroups per CU

@@ -814,6 +814,18 @@ size_t stream_fused_workspace(uint64_t capacity) {
     return static_cast<size_t>(reinterpret_cast<uintptr_t>(side.flags)) + 256;
 }
 
+static int stream_eval_waves_asked() {
+    static const int waves_env = getenv("RT_DP_STREAM_WAVES") ? atoi(getenv("RT_DP_STREAM_WAVES")) : -1;
+    return (waves_env >= 0 && waves_env <= 32) ? waves_env : kStreamEvalWavesPerCu;
+}
+
+int stream_eval_waves_per_cu() {
+    const int waves = stream_eval_waves_asked();
+    int achieved = 0;
+    if (waves > 0) (void)residency_pad(reinterpret_cast<const void *>(&k_stream_eval), 64, waves, &achieved);
+    return achieved;
+}
+
 // One piece of n <= capacity records.  first_piece: also clears the sticky "opcode > 3" word, once per call.
 hipError_t stream_fused_eval(const uint32_t *in, uint64_t n, uint64_t capacity, int extended, uint32_t *out, char *workspace,
                              StreamSideView *view, hipStream_t s, bool first_piece) {
@@ -825,8 +837,7 @@ hipError_t stream_fused_eval(const uint32_t *in, uint64_t n, uint64_t capacity, 
     // Eight or nine waves per CU: with fewer the kernel's instructions are not covered, with more the memory system sees more
     // open 21 KiB spans than it serves well (MI355X, ms per call at 2^22 / 2^24 / 2^26 records: 7 waves 0.377 / 1.27 / 4.85,
     // 8: 0.355 / 1.22 / 4.85, 9: 0.340 / 1.22 / 4.90, 12: 0.350 / 1.30 / 5.36).
-    static const int waves_env = getenv("RT_DP_STREAM_WAVES") ? atoi(getenv("RT_DP_STREAM_WAVES")) : -1;
-    const int waves = waves_env >= 0 ? waves_env : kStreamEvalWavesPerCu;
+    const int waves = stream_eval_waves_asked();
     const unsigned pad = waves > 0 ? residency_pad(reinterpret_cast<const void *>(&k_stream_eval), 64, waves) : 0u;
     hipLaunchKernelGGL(k_stream_eval, dim3((unsigned)nblk), dim3(64), pad, s, in, n, extended, out, side);
     if (extended) hipLaunchKernelGGL(k_stream_bits, dim3((unsigned)(((nblk + 63) / 64 + 255) / 256)), dim3(256), 0, s, side, nblk);

@@ -21,6 +21,7 @@ def test_resolved_residency_is_the_default_table(torch_cuda, ctx):
     requested through dynamic LDS, and the occupancy query of the runtime must agree that it took."""
     assert ctx.get_option("box_wgs_per_cu") == 3
     assert ctx.get_option("tri_wgs_per_cu") == 5
+    assert ctx.get_option("stream_waves_per_cu") == 8      # the record-stream evaluation kernel's cap took as well
     for w in (3, 4, 6, 8):
         ctx.set_option("wgs_per_cu", w)
         assert ctx.get_option("wgs_per_cu") == w
