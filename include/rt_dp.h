@@ -320,7 +320,8 @@ int rt_dp_eval_bundles(rt_dp_ctx *ctx, const rt_dp_input_bundle *in, rt_dp_outpu
 
 /* The same contract for a record stream that already lives in HBM (device pointers,
  * n < 2^29); everything runs on the GPU and the records are read once, in place.  With
- * 16-byte aligned arrays (option "stream_mode" 0 / 2) one kernel evaluates every record
+ * a 16-byte aligned input array (option "stream_mode" 0 / 2; the output array may be a
+ * slice that starts at any record of a larger one) one kernel evaluates every record
  * where it lies and a second, small one adds the distance beats that continue a vector
  * pair from an earlier part of the stream onto that pair's running sum, in stream order;
  * the context keeps a workspace of about 12.6 bytes per record of a piece (pieces of at
@@ -640,7 +641,7 @@ int rt_dp_set_tuning(rt_dp_ctx *ctx, int ops_per_lane, int nontemporal, int vec_
  * "stream_mode" selects how rt_dp_eval_bundles_device works: 1 partitions the
  * records by opcode into structure-of-arrays segments first, 2 evaluates them in place and then adds up
  * the distance beats in a second kernel, 3 does both in one pass with the running sums handed from wave to
- * wave (2 and 3 need 16-byte aligned record arrays; same results, 2 is the fastest on MI355X),
+ * wave (2 and 3 need a 16-byte aligned input record array; same results, 2 is the fastest on MI355X),
  * 0 (default) picks 2 when the alignment allows. */
 int rt_dp_set_option(rt_dp_ctx *ctx, const char *key, int value);
 /* Reads a knob back as the library resolved it: the keys above give the value in effect ("ops_per_lane",

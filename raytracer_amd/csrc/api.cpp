@@ -861,9 +861,11 @@ static int bundles_device(rt_dp_ctx *ctx, const rt_dp_input_bundle *d_in, rt_dp_
         have = want;
         return RT_DP_OK;
     };
-    const bool aligned16 = ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15u) == 0;
+    // the in-place paths read the records in 16-byte pieces; the output records may start anywhere (a slice of a larger array
+    // starts at a multiple of 84 bytes)
+    const bool aligned16 = (reinterpret_cast<uintptr_t>(d_in) & 15u) == 0;
     if ((ctx->stream_mode == 2 || ctx->stream_mode == 3) && !aligned16)
-        return fail(RT_DP_EALIGN, "the fused record-stream paths need 16-byte aligned record arrays");
+        return fail(RT_DP_EALIGN, "the in-place record-stream paths need a 16-byte aligned input record array");
     if (ctx->stream_mode == 3) {
         // ONE pass over the records: every wave evaluates its 64 records and adds up its distance beats in stream order,
         // the running sums travel from wave to wave (stream_fused.hip: k_stream_chain).  Pieces of 2^26 records bound

@@ -211,6 +211,24 @@ __device__ __forceinline__ bool stream_eval_compact(const u4v *rc, uint32_t op_i
     return known;
 }
 
+// The wave's output records (live * 21 words, assembled in LDS) to HBM.  A whole wave's 5376 bytes go out in 16-byte pieces when
+// the output array is 16-byte aligned (the records of a wave start 5376 = 16 * 336 bytes apart), in coalesced 4-byte pieces when
+// it is not: an output array that is a slice of a larger one starts at a multiple of 84 bytes.
+__device__ __forceinline__ void stream_store_records(const uint32_t *s_rec, uint32_t *dst, uint32_t live, int lane) {
+    if (live == (uint32_t)kWaveRecs && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {  // 1344 words = 336 chunks of 16 bytes
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int g = j * 64 + lane;
+            if (g < kWaveRecs * kRecOut / 4) __builtin_nontemporal_store(reinterpret_cast<const u4v *>(s_rec)[g], reinterpret_cast<u4v *>(dst) + g);
+        }
+    } else if (live == (uint32_t)kWaveRecs) {
+#pragma unroll
+        for (int k = 0; k < kRecOut; ++k) __builtin_nontemporal_store(s_rec[k * 64 + lane], dst + k * 64 + lane);
+    } else {
+        for (uint32_t g = lane; g < live * kRecOut; g += 64) dst[g] = s_rec[g];
+    }
+}
+
 constexpr int kStreamEvalWavesPerCu = 8;  // resident waves of k_stream_eval per CU (environment RT_DP_STREAM_WAVES: another number, 0 = whatever fits)
 constexpr int kStageWords = (kWaveRecs * kLiveStride + kWaveRecs) * 4;  // the compact rows and, behind them, one slot per lane for chunks nobody reads
 
@@ -318,16 +336,7 @@ __global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__
 #pragma unroll
     for (int k = 0; k < kRecOut; ++k) s_rec[lane * kRecOut + k] = w[k];  // stride 21 words is odd: conflict-free
     __syncthreads();
-    uint32_t *dst = out + r0 * kRecOut;
-    if (live == (uint32_t)kWaveRecs) {  // 1344 words = 336 chunks of 16 bytes
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int g = j * 64 + lane;
-            if (g < kWaveRecs * kRecOut / 4) __builtin_nontemporal_store(reinterpret_cast<const u4v *>(s_rec)[g], reinterpret_cast<u4v *>(dst) + g);
-        }
-    } else {
-        for (uint32_t g = lane; g < live * kRecOut; g += 64) dst[g] = s_rec[g];
-    }
+    stream_store_records(s_rec, out + r0 * kRecOut, live, lane);
 }
 
 // The per-wave bytes of k_stream_eval become one bit per wave (64 waves per word) and the "opcode occurs" flags.
@@ -712,16 +721,7 @@ __global__ __launch_bounds__(64) void k_stream_chain(const uint32_t *__restrict_
 #pragma unroll
     for (int k = 0; k < kRecOut; ++k) s_rec[lane * kRecOut + k] = w[k];  // stride 21 words is odd: conflict-free
     __syncthreads();
-    uint32_t *dst = out + r0 * kRecOut;
-    if (live == (uint32_t)kWaveRecs) {  // 1344 words = 336 chunks of 16 bytes
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int g = j * 64 + lane;
-            if (g < kWaveRecs * kRecOut / 4) __builtin_nontemporal_store(reinterpret_cast<const u4v *>(s_rec)[g], reinterpret_cast<u4v *>(dst) + g);
-        }
-    } else {
-        for (uint32_t g = lane; g < live * kRecOut; g += 64) dst[g] = s_rec[g];
-    }
+    stream_store_records(s_rec, out + r0 * kRecOut, live, lane);
 }
 
 // The registers behind the last record: the sum published by the last wave that is not transparent (the words are final

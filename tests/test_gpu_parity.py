@@ -412,6 +412,29 @@ def test_device_record_stream_carries_accumulators(oracle, torch_cuda, mode):
     c.close()
 
 
+@pytest.mark.parametrize("mode", [0, 2, 3])
+def test_record_stream_into_slices_of_one_output_array(oracle, torch_cuda, mode):
+    """Pieces of a stream evaluated straight into their places in ONE output array: a piece that starts at record k starts
+    84 k bytes into it, which is 16-byte aligned for every fourth k only; the in-place paths take any."""
+    torch = torch_cuda
+    stream = _mixed_stream(17, 4000, 3000, 500, 600)
+    n = stream.shape[0]
+    want, state = oracle.eval_bundles("B", stream.view(oracle.IN_BUNDLE).reshape(-1), extended=True)
+    d_in = torch.from_numpy(stream.view(np.int32)).cuda()
+    d_out = torch.full((n + 3, 21), -1, dtype=torch.int32, device="cuda")
+    c = capi.Context()
+    c.set_option("stream_mode", mode)
+    cuts = [0, 1, 2, 3, 67, 130, 1001, 4098, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        assert (d_in[a:b].data_ptr() & 15) == 0 and ((d_out[a:b].data_ptr() & 15) == 0) == (a % 4 == 0)
+        c.eval_bundles_device(d_in[a:b], d_out[a:b])
+    got = d_out.cpu().numpy().view(u32)
+    assert_bits_equal(got[:n], want.view(u32).reshape(-1, 21), "records written into slices")
+    assert (got[n:] == 0xFFFFFFFF).all(), "records behind the last slice were touched"
+    assert tuple(int(x) for x in c.get_accum().view(u32)) == state
+    c.close()
+
+
 def _single_pass_case(oracle, torch, stream, what, chunk_log2=None, monkeypatch=None, mode=3):
     """One stream through the single-pass record-stream kernel against oracle B, registers included, twice in a row on one
     context (the second call continues the first one's registers)."""
