@@ -280,7 +280,12 @@ __global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__
     __shared__ __align__(16) uint32_t s_rec[kStageWords];  // 12 KiB: live chunks and spare slots; re-used for the output records (5.25 KiB)
     __shared__ uint32_t s_op[kWaveRecs + 1];  // one entry more: the chunk walk of stream_stage ends one record behind the wave's last
     const int lane = threadIdx.x;
-    const uint64_t r0 = (uint64_t)blockIdx.x * kWaveRecs;
+    // Workgroups go to the eight XCDs in turn (workgroup i to XCD i mod 8): XCD x works through the x-th eighth of the stream,
+    // so that the waves resident on one XCD read neighbouring spans.
+    const uint64_t nblk = (n + kWaveRecs - 1) / kWaveRecs, per = (nblk + 7) / 8;
+    const uint64_t span = (uint64_t)(blockIdx.x & 7u) * per + (blockIdx.x >> 3);  // = the "wave" index of the side arrays
+    if (span >= nblk) return;
+    const uint64_t r0 = span * kWaveRecs;
     const uint32_t live = (n - r0 < (uint64_t)kWaveRecs) ? (uint32_t)(n - r0) : (uint32_t)kWaveRecs;
 
     stream_stage(in, r0, live, lane, s_rec, s_op);
@@ -326,9 +331,9 @@ __global__ __launch_bounds__(64) void k_stream_eval(const uint32_t *__restrict__
         // wave (an earlier form set summary bits and launch flags with atomics guarded by a device-scope load of the flag:
         // one more memory round trip per wave).
         if (lane == 0) {
-            side.heads[blockIdx.x] = u4v{(uint32_t)h2, (uint32_t)(h2 >> 32), (uint32_t)h3, (uint32_t)(h3 >> 32)};
-            side.tails[blockIdx.x] = u4v{__float_as_uint(tail_e), __float_as_uint(tail_d), __float_as_uint(tail_n), 0u};
-            side.wavebits[blockIdx.x] = (uint8_t)((e2 ? 1u : 0u) | (e3 ? 2u : 0u) | (r2 ? 4u : 0u) | (r3 ? 8u : 0u));
+            side.heads[span] = u4v{(uint32_t)h2, (uint32_t)(h2 >> 32), (uint32_t)h3, (uint32_t)(h3 >> 32)};
+            side.tails[span] = u4v{__float_as_uint(tail_e), __float_as_uint(tail_d), __float_as_uint(tail_n), 0u};
+            side.wavebits[span] = (uint8_t)((e2 ? 1u : 0u) | (e3 ? 2u : 0u) | (r2 ? 4u : 0u) | (r3 ? 8u : 0u));
         }
     }
 
@@ -839,7 +844,7 @@ hipError_t stream_fused_eval(const uint32_t *in, uint64_t n, uint64_t capacity, 
     // 8: 0.355 / 1.22 / 4.85, 9: 0.340 / 1.22 / 4.90, 12: 0.350 / 1.30 / 5.36).
     const int waves = stream_eval_waves_asked();
     const unsigned pad = waves > 0 ? residency_pad(reinterpret_cast<const void *>(&k_stream_eval), 64, waves) : 0u;
-    hipLaunchKernelGGL(k_stream_eval, dim3((unsigned)nblk), dim3(64), pad, s, in, n, extended, out, side);
+    hipLaunchKernelGGL(k_stream_eval, dim3((unsigned)(((nblk + 7) / 8) * 8)), dim3(64), pad, s, in, n, extended, out, side);
     if (extended) hipLaunchKernelGGL(k_stream_bits, dim3((unsigned)(((nblk + 63) / 64 + 255) / 256)), dim3(256), 0, s, side, nblk);
     view->hs[0] = side.hs[0]; view->hs[1] = side.hs[1]; view->hs[2] = side.hs[2]; view->heads = side.heads; view->tails = side.tails;
     view->occ[0] = side.occ[0]; view->occ[1] = side.occ[1]; view->rst[0] = side.rst[0]; view->rst[1] = side.rst[1]; view->flags = side.flags;
