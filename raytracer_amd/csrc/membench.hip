@@ -302,6 +302,69 @@ static void token_probes(void *a, void *b, size_t bytes) {
     run_rec_token<1, false, 16>("1 wave x12, free, work 16", a, b, n_rec, 11520);
 }
 
+// The beat kernels' memory pattern (512-beat tiles, 16-byte operand loads, one control word and one or two result words per
+// beat, results staged through LDS) over separate arrays a / b / ctl / out0 / out1 and over a fused layout in which a tile's
+// operands and control words (and its results) are contiguous: would a tiled layout for beats raise their ceiling?
+template <bool EUC, bool FUSED>
+__global__ __launch_bounds__(256) void k_beatpat(const float *in, float *out, size_t n) {
+    constexpr int ROW = EUC ? 16 : 8, LPB = ROW / 4, BPP = 256 / LPB, PASSES = EUC ? 8 : 4, SUB = PASSES * BPP;
+    __shared__ float s0[SUB], s1[SUB];
+    const int tid = threadIdx.x, part = tid % LPB;
+    const size_t tile = blockIdx.x, base = tile * SUB;
+    if (base + SUB > n) return;
+    const float *a, *b;
+    const uint32_t *ctl;
+    float *o0, *o1;
+    if (FUSED) {
+        const float *t = in + tile * (size_t)(2 * SUB * ROW + SUB);
+        a = t; b = t + (size_t)SUB * ROW; ctl = reinterpret_cast<const uint32_t *>(t + (size_t)2 * SUB * ROW);
+        o0 = out + tile * (size_t)(2 * SUB); o1 = o0 + SUB;
+    } else {
+        a = in + base * ROW; b = in + n * ROW + base * ROW; ctl = reinterpret_cast<const uint32_t *>(in + 2 * n * ROW) + base;
+        o0 = out + base; o1 = out + n + base;
+    }
+    f4v va[PASSES], vb[PASSES];
+    uint32_t vc[PASSES];
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+        const int bl = u * BPP + tid / LPB;
+        va[u] = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(a + (size_t)bl * ROW + part * 4));
+        vb[u] = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(b + (size_t)bl * ROW + part * 4));
+        vc[u] = __builtin_nontemporal_load(ctl + bl);
+    }
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+        const int bl = u * BPP + tid / LPB;
+        const f4v p = va[u] * vb[u];
+        const float r = (p.x + p.y) + (p.z + p.w) + (float)vc[u];
+        if (part == 0) { s0[bl] = r; s1[bl] = r * 2.0f; }
+    }
+    __syncthreads();
+    for (int t0 = tid; t0 < SUB; t0 += 256) {
+        __builtin_nontemporal_store(s0[t0], o0 + t0);
+        if (!EUC) __builtin_nontemporal_store(s1[t0], o1 + t0);
+    }
+}
+
+template <bool EUC, bool FUSED> static void run_beatpat(const char *name, const void *in, void *out, size_t n, unsigned lds) {
+    constexpr int SUB = 512;
+    const unsigned blocks = (unsigned)(n / SUB);
+    double ms = time_ms([&] { hipLaunchKernelGGL((k_beatpat<EUC, FUSED>), dim3(blocks), dim3(256), lds, 0, (const float *)in, (float *)out, n); });
+    const double bytes = (double)n * (EUC ? 136.0 : 76.0);
+    printf("%-44s lds %6u  %8.1f GB/s  (%.3f ms)\n", name, lds, bytes / ms / 1e6, ms);
+}
+
+static void beat_probes(void *a, void *b) {
+    const size_t n = (size_t)1 << 24;
+    const unsigned caps[] = {0u, 12800u, 19200u, 26880u, 32000u};  // as many as fit, then 7 / 6 / 5 / 4 workgroups per CU with the 4 KiB of the kernel
+    for (unsigned lds : caps) {
+        run_beatpat<false, false>("angular pattern, separate arrays", a, b, n, lds);
+        run_beatpat<false, true>("angular pattern, fused tiles", a, b, n, lds);
+        run_beatpat<true, false>("euclidean pattern, separate arrays", a, b, n, lds);
+        run_beatpat<true, true>("euclidean pattern, fused tiles", a, b, n, lds);
+    }
+}
+
 int main(int argc, char **argv) {
     // second argument: resident 256-thread workgroups per CU (LDS granules of 1280 B, 128 per CU); 0 = whatever fits
     if (argc > 2 && atoi(argv[2]) >= 3) g_lds = (128u / (unsigned)atoi(argv[2])) * 1280u;
@@ -312,6 +375,12 @@ int main(int argc, char **argv) {
     CK(hipMemset(a, 0x11, bytes));
     CK(hipMemset(b, 0x22, bytes));
     CK(hipDeviceSynchronize());
+    if (argc > 3 && !strcmp(argv[3], "beat")) {  // the beat kernels' pattern, separate arrays against fused tiles
+        beat_probes(a, b);
+        CK(hipFree(a));
+        CK(hipFree(b));
+        return 0;
+    }
     if (argc > 3 && !strcmp(argv[3], "token")) {  // throttled load phases
         CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_token<12, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 140000));
         CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_token<12, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 140000));
