@@ -467,9 +467,9 @@ def stream_measure(a, world, rank, local, dev, log2_n, mode, steps, warmup):
 def run_stream(a, world, rank, local, dev):
     r = stream_measure(a, world, rank, local, dev, a.log2_ops, a.stream_mode, a.steps, a.warmup)
     if rank == 0:
-        print(json.dumps({"metric": r["metric"], "value": r["value"], "unit": r["unit"], "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        emit({"metric": r["metric"], "value": r["value"], "unit": r["unit"], "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                           "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-                          "data": "synthetic", "config": {"workload": r["workload"]}, "roofline": r["roofline"]}), flush=True)
+                          "data": "synthetic", "config": {"workload": r["workload"]}, "roofline": r["roofline"]})
     dist_util.shutdown()
 
 
@@ -516,13 +516,13 @@ def run_trace(a, world, rank, local, dev):
     if rank == 0:
         per = wall / a.steps
         hits = float((out_i != -1).float().mean().item())
-        print(json.dumps({"metric": "rays/s (closest hit, BVH4 %s traversal on the datapath ops)" % ("wavefront" if a.trace_wavefront else "depth-first"), "value": round(n_rays * world / per, 1),
+        emit({"metric": "rays/s (closest hit, BVH4 %s traversal on the datapath ops)" % ("wavefront" if a.trace_wavefront else "depth-first"), "value": round(n_rays * world / per, 1),
                           "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(per * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "trace: 2^%d triangles, 2^%d %s rays per GPU, leaf size 4, hierarchy built on the %s in %.4f s (not timed)" % (
                               a.trace_log2_tris, a.trace_log2_rays, "cell-sorted" if a.trace_sorted else "unsorted", a.trace_build, build_s)},
                           "per_call": {k: int(v) for k, v in stats.items()}, "hit_fraction": round(hits, 4),
-                          "box_ops_per_s": round(stats["box_ops"] / per, 1), "tri_ops_per_s": round(stats["tri_ops"] / per, 1)}), flush=True)
+                          "box_ops_per_s": round(stats["box_ops"] / per, 1), "tri_ops_per_s": round(stats["tri_ops"] / per, 1)})
     ctx.close()
     dist_util.shutdown()
 
@@ -603,11 +603,11 @@ def run_knn(a, world, rank, local, dev):
     ctx = capi.Context(device=local)
     r = knn_measure(a, ctx, world, rank, dev, a.knn_tree, a.steps, a.warmup)
     if rank == 0:
-        print(json.dumps({"metric": r["metric"], "value": r["value"], "unit": r["unit"], "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        emit({"metric": r["metric"], "value": r["value"], "unit": r["unit"], "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                           "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                           "data": "synthetic", "config": {"workload": r["workload"]}, "search": r["search"],
                           "pair_rate_equivalent_per_s": r["pair_rate_equivalent_per_s"], "valu": r["valu"], "exchange": r["exchange"],
-                          "leaves_scanned_fraction": r.get("leaves_scanned_fraction")}), flush=True)
+                          "leaves_scanned_fraction": r.get("leaves_scanned_fraction")})
     ctx.close()
     dist_util.shutdown()
 
@@ -747,8 +747,30 @@ def resolved_tuning(ctx, a):
     return t
 
 
+_RESULT_OUT = None
+
+
+def claim_stdout():
+    """Keeps the process's standard output for the result line alone: file descriptor 1 is pointed at standard error for
+    everything else (libraries below Python print there too: gloo announces its connections on stdout), and emit() writes
+    the JSON line to the descriptor that was standard output when the process started."""
+    global _RESULT_OUT
+    if _RESULT_OUT is None:
+        sys.stdout.flush()
+        _RESULT_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = json.dumps(obj)
+    out = _RESULT_OUT if _RESULT_OUT is not None else sys.stdout
+    out.write(line + "\n")
+    out.flush()
+
+
 def main():
     a = parse()
+    claim_stdout()
     world, rank, local = dist_util.env_world()
     if a.gpus != world and rank == 0:
         print("bench.py: --gpus %d but the launch environment has %d rank(s); reporting n_gpus = %d" % (a.gpus, world, world), file=sys.stderr)
@@ -783,13 +805,13 @@ def main():
     if a.only == "mixed" and a.strong:
         r = strong_mixed_measure(a, ctx, world, rank, dev, dist, a.strong_log2_ops, a.steps, a.warmup)
         if rank == 0:
-            print(json.dumps({"metric": "datapath ops/s (mixed opcodes, one stream sharded over the GPUs)", "value": r["value"], "unit": "ops/s",
+            emit({"metric": "datapath ops/s (mixed opcodes, one stream sharded over the GPUs)", "value": r["value"], "unit": "ops/s",
                               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
                               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                               "config": {"workload": r["workload"], "units_whole_job": r["units_whole_job"], "units_this_gpu": r["units_this_gpu"],
                                          "sharding": "shard.plan: contiguous ranges per opcode segment, beat segments cut on vector-pair boundaries", "tuning": tuning},
                               "roofline": r["roofline"], "cpu_baseline": None,
-                              "verified_against_whole_stream": r.get("verified_against_whole_stream")}), flush=True)
+                              "verified_against_whole_stream": r.get("verified_against_whole_stream")})
         ctx.close()
         dist_util.shutdown()
         return
@@ -801,11 +823,11 @@ def main():
         wall, dev_ms = run_pack(ctx, fields, tiled_buf, n, a.steps, a.warmup, dist)
         moved = 2 * 4 * len(fields) * n
         if rank == 0:
-            print(json.dumps({"metric": "ops/s packed (rt_dp_tile_pack, 34 operand arrays -> tiled box segment)", "value": round(n * world * a.steps / wall, 1), "unit": "ops/s",
+            emit({"metric": "ops/s packed (rt_dp_tile_pack, 34 operand arrays -> tiled box segment)", "value": round(n * world * a.steps / wall, 1), "unit": "ops/s",
                               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(wall / a.steps * 1e3, 4), "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": {"workload": "pack: %d box ops per GPU" % n},
                               "roofline": {"bound": "hbm", "achieved": round(moved / dev_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                           "frac": round(moved / dev_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(dev_ms, 4)}, "cpu_baseline": None}), flush=True)
+                                           "frac": round(moved / dev_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(dev_ms, 4)}, "cpu_baseline": None})
         ctx.close()
         dist_util.shutdown()
         return
@@ -822,7 +844,7 @@ def main():
 
     if a.sweep:
         for row in sweep(ctx, batches, which):
-            print(json.dumps(row), flush=True)
+            emit(row)
         ctx.close()
         return
 
@@ -948,7 +970,7 @@ def main():
                                   "layout": v.get("layout", "plain"), "roofline": v["roofline"], **({"edge_classes": v["edge_classes"]} if "edge_classes" in v else {})}
                               for k, v in results.items()}
         line["per_opcode"].update(extras)
-        print(json.dumps(line), flush=True)
+        emit(line)
     ctx.close()
     dist_util.shutdown()
 

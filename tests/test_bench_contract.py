@@ -19,6 +19,7 @@ SMALL = ["--strong-log2-ops", "20", "--knn-log2-points", "14", "--knn-log2-queri
 def check_line(out, n_gpus, steps, warmup, scaling="weak"):
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out[-2000:]
+    assert [l for l in out.splitlines() if l.strip()] == lines, "standard output carries more than the result line: " + out[:500]
     d = json.loads(lines[0])
     for f in FIELDS:
         assert f in d, f
